@@ -1,0 +1,144 @@
+/* nasr.h — C ABI of libnasr.so: the MI355X (gfx950) implementation of NeuralASR's CTC training
+ * hot path ((Bi)LSTM stack -> affine projection -> CTC loss/gradient -> Adam), one handle per
+ * GPU / process.
+ *
+ * The reference has no FFI: its hot path is a TensorFlow-1 graph driven from Python
+ * (/root/reference/networks/tfnetwork.py).  Each entry point below names the reference
+ * interface it replaces; the Python `Network` subclass in neuralasr_amd/networks binds them
+ * with ctypes (INTEGRATION.md shows the stub a NeuralASR maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; nasr_last_error() gives the message
+ *     (NASR_ERR_INFEASIBLE mirrors TF's "Not enough time for target transition sequence").
+ *   - the caller owns every host buffer; the library owns all device memory.
+ *   - one host thread per handle; a handle is not re-entrant (tfnetwork.py: one Session).
+ *   - features are batch-major float32 [B,T,F] C-contiguous, zero past seq_len (dataset.py:75-77);
+ *     labels int32 [B,Lmax] padded with 0; label ids in [0, C-2]; blank = C-1 (A.4).
+ *   - flat parameter / gradient order is TF variable order: per layer (fw kernel [I+H,4H] rows
+ *     [input;h], gate columns i,j,f,o; fw bias [4H]; bw kernel; bw bias) or (kernel, bias);
+ *     then W [Hin,C], b [C]  (SURVEY.md §8b, Appendix A.1).
+ *   - there is NO CPU fallback: nasr_create fails when no gfx950 device is usable.
+ */
+#ifndef NASR_H
+#define NASR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NASR_OK 0
+#define NASR_ERR_ARG (-1)        /* bad argument / shape */
+#define NASR_ERR_HIP (-2)        /* HIP runtime error */
+#define NASR_ERR_INFEASIBLE (-3) /* CTC: label needs more frames than seq_len (TF InvalidArgument) */
+#define NASR_ERR_STATE (-4)      /* call order (e.g. backward without a resident batch) */
+
+#define NASR_MERGE_NONE 0          /* unidirectional (networks/lstm_ctc_net.py:17-23) */
+#define NASR_MERGE_STACK_RESHAPE 1 /* literal BiLstmCTCNet: tf.reshape on the (fw,bw) tuple
+                                      (networks/bilstm_ctc_net.py:33,45) */
+#define NASR_MERGE_CONCAT 2        /* tf.concat(outputs, 2) (networks/deepspeech.py:103) */
+
+typedef struct nasr_ctx* nasr_handle;
+
+/* Model + optimiser shape.  Replaces the hard-coded locals of create_network
+ * (networks/bilstm_ctc_net.py:14, networks/lstm_ctc_net.py:14-15) and the AdamOptimizer
+ * defaults of setup_training_network (networks/tfnetwork.py:116-117). */
+typedef struct {
+  int32_t feature_size;  /* F = (2*numcontext+1)*numcep  (config.py:25) */
+  int32_t hidden;        /* H: LSTM units per direction */
+  int32_t num_layers;
+  int32_t bidirectional; /* 0 | 1 */
+  int32_t merge;         /* NASR_MERGE_* */
+  int32_t num_classes;   /* C = symbols.counter (networks/tfnetwork.py:18); blank = C-1 */
+  float forget_bias;     /* 1.0 (BasicLSTMCell / LSTMCell default) */
+  float learning_rate;   /* config.learningrate */
+  float beta1, beta2, epsilon; /* 0.9, 0.999, 1e-8 */
+} nasr_model_cfg;
+
+/* Phase timings of the last nasr_compute_grads / nasr_apply_adam (HIP events on the handle's
+ * stream), milliseconds.  Used by bench.py's roofline object. */
+typedef struct {
+  float pack_ms;      /* feature transpose+pad into time-major HBM layout */
+  float xproj_ms;     /* input-to-hidden GEMMs (all layers) */
+  float rec_fwd_ms;   /* forward recurrence: all layers' per-timestep kernels */
+  float proj_ctc_ms;  /* projection GEMM + CTC (logZ, alpha/beta, gradient) */
+  float proj_bwd_ms;  /* projection backward GEMMs */
+  float rec_bwd_ms;   /* BPTT: all layers' per-timestep kernels */
+  float wgrad_ms;     /* weight-gradient / input-gradient GEMMs + bias column sums */
+  float adam_ms;      /* fused Adam + recurrent-weight repack */
+  float total_ms;
+  int32_t rec_fwd_launches; /* number of forward step-kernel launches in rec_fwd_ms */
+  int32_t rec_bwd_launches;
+} nasr_phase_times;
+
+/* ---- lifetime ---------------------------------------------------------------------------
+ * nasr_create replaces TensorFlowNetwork.__init__ graph construction + tf.Session
+ * (networks/tfnetwork.py:14-43).  `stream` is a hipStream_t to launch on (NULL: the library
+ * creates its own); pass torch.cuda.current_stream().cuda_stream to order the handle's work
+ * with torch.distributed collectives.  Parameters start at zero: call nasr_set_params. */
+int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_handle* out);
+int nasr_destroy(nasr_handle h);
+const char* nasr_last_error(nasr_handle h); /* h may be NULL: error of a failed nasr_create */
+const char* nasr_backend(nasr_handle h);    /* "hip-gfx950" */
+int nasr_synchronize(nasr_handle h);        /* hipStreamSynchronize on the handle's stream */
+
+/* ---- parameters / optimiser state (replaces tf.train.Saver's view of the variables,
+ * networks/tfnetwork.py:40,142-164; TF variable order) ------------------------------------ */
+int64_t nasr_param_count(nasr_handle h);
+int nasr_num_tensors(nasr_handle h);
+/* name (<=63 chars), offset into the flat vector, rows, cols (cols = 1 for vectors) */
+int nasr_tensor_info(nasr_handle h, int idx, char name[64], int64_t* offset, int64_t* rows, int64_t* cols);
+int nasr_set_params(nasr_handle h, const float* flat, int64_t n);
+int nasr_get_params(nasr_handle h, float* flat, int64_t n);
+int nasr_set_adam_state(nasr_handle h, const float* m, const float* v, int64_t n, int64_t step);
+int nasr_get_adam_state(nasr_handle h, float* m, float* v, int64_t n, int64_t* step);
+int nasr_set_learning_rate(nasr_handle h, float lr);
+
+/* ---- one-call entry points over host buffers -------------------------------------------
+ * nasr_train_step replaces sess.run([optimizer, loss]) of TensorFlowNetwork.train
+ * (networks/tfnetwork.py:183-190) for one tower: forward, CTC, backward, Adam.  loss_out =
+ * reduce_mean of the per-utterance CTC NLL (networks/tfnetwork.py:59). */
+int nasr_train_step(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                    const int32_t* label_len, int B, int T, int Lmax, float* loss_out);
+/* forward only (inference graph, networks/tfnetwork.py:33-37): logits_out is time-major
+ * [T',B,C] with T' = nasr_logit_frames(h,T) (2T for STACK_RESHAPE). May be NULL. */
+int nasr_forward(nasr_handle h, const float* feats, const int32_t* seq_len, int B, int T, float* logits_out);
+int nasr_logit_frames(nasr_handle h, int T);
+/* loss of validate()/evaluate() (networks/tfnetwork.py:166-177): forward + CTC, no update.
+ * nll_out [B] per-utterance (may be NULL). */
+int nasr_loss(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+              const int32_t* label_len, int B, int T, int Lmax, float* loss_out, float* nll_out);
+/* parity hook: loss + d loss/d every variable, TF order, no update.  flat_grads_out [param_count]. */
+int nasr_loss_and_grads(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                        const int32_t* label_len, int B, int T, int Lmax, float* loss_out, float* nll_out,
+                        float* flat_grads_out);
+/* tf.nn.ctc_greedy_decoder(merge_repeated=True), the decoder named at networks/tfnetwork.py:62-63:
+ * ids_out [B, T'] (row b holds lens_out[b] ids), lens_out [B]. */
+int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len, int B, int T,
+                       int32_t* ids_out, int32_t* lens_out);
+
+/* ---- data-parallel building blocks (one shard per GPU; replaces make_parallel +
+ * average_gradients, networks/tfnetwork.py:72-140).  Typical step on every rank:
+ *   nasr_upload_batch(shard) ; nasr_compute_grads ; all-reduce(sum) nasr_grad_device_ptr over
+ *   RCCL ; nasr_apply_adam(1/world) ; nasr_get_loss
+ * The gradient buffer is one flat fp32 device array of nasr_grad_device_count elements in the
+ * library's padded internal layout (identical on every rank; padding elements are always 0). */
+int nasr_upload_batch(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                      const int32_t* label_len, int B, int T, int Lmax);
+int nasr_compute_grads(nasr_handle h);          /* forward+CTC+backward on the resident batch (async) */
+void* nasr_grad_device_ptr(nasr_handle h);
+int64_t nasr_grad_device_count(nasr_handle h);
+int nasr_apply_adam(nasr_handle h, float grad_scale); /* g*grad_scale, TF Adam, step += 1 (async) */
+int nasr_get_loss(nasr_handle h, float* loss_out);    /* synchronises; loss of last compute_grads */
+int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the resident batch */
+
+/* ---- measurement ------------------------------------------------------------------------ */
+int nasr_set_profiling(nasr_handle h, int enabled); /* record HIP events around the phases */
+int nasr_get_phase_times(nasr_handle h, nasr_phase_times* out); /* synchronises */
+int nasr_set_graph_mode(nasr_handle h, int enabled); /* capture the per-timestep loops in hipGraphs */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NASR_H */

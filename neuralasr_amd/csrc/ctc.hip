@@ -1,0 +1,344 @@
+// ctc.hip — tf.nn.ctc_loss (networks/tfnetwork.py:58-59) forward-backward and its gradient, and the
+// greedy decoder named at networks/tfnetwork.py:62-63, as gfx950 kernels.
+//
+// Semantics: unnormalised time-major logits [T',B,C], blank = C-1, softmax over C
+// for t < seq_len[b]; extended label l' (blanks interleaved), S = 2L+1;
+//   alpha(u,t) = log y(l'_u,t) + LSE(alpha(u,t-1), alpha(u-1,t-1), [alpha(u-2,t-1) if l'_u != blank, != l'_{u-2}])
+//   beta (TF convention: excludes the emission at t), log p = LSE_u(alpha+beta),
+//   d nll / d logit(t,k) = y(t,k) - exp(LSE_{u: l'_u = k}(alpha+beta) - log p), zero for t >= seq_len.
+//
+// Kernel split: (1) logZ per (t,b) row, one wave per row; (2) alpha and beta recursions, one workgroup per
+// utterance, wave 0 = alpha, wave 1 = beta, the lattice column lives in registers (KS consecutive states per
+// lane), neighbours come over wave shuffles, so a timestep has no barrier and no LDS; emissions are
+// prefetched four frames ahead; (3) gradient, one wave per (t,b) row, class posteriors binned in LDS.
+#include "kernels.h"
+
+namespace nasr {
+
+constexpr float NEG = -1e30f;
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------ (1) log partition per row
+__global__ __launch_bounds__(256) void ctc_logz_kernel(const float* __restrict__ logits, const int* __restrict__ seq_len,
+                                                       float* __restrict__ logz, int Tp, int B, int Bp, int C, int Cp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= Tp * Bp) return;
+  const int t = row / Bp, b = row % Bp;
+  if (b >= B || t >= seq_len[b]) return;
+  const float* x = logits + (size_t)row * Cp;
+  float m = NEG;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(x[c] - m);
+  s = wave_sum(s);
+  if (lane == 0) logz[row] = m + __logf(s);
+}
+
+void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, float* logz, hipStream_t st) {
+  const int rows = d.Tp * d.Bp;
+  hipLaunchKernelGGL(ctc_logz_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, seq_len, logz, d.Tp, d.B, d.Bp,
+                     d.C, d.Cp);
+}
+
+// ------------------------------------------------------------------ (2) alpha / beta
+// workspace layout: alpha[b][t][i][lane] with state s = lane*KS + i
+template <int KS>
+__global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
+    const float* __restrict__ logits, const float* __restrict__ logz, const int* __restrict__ labels,
+    const int* __restrict__ label_len, const int* __restrict__ seq_len, float* __restrict__ alpha,
+    float* __restrict__ beta, float* __restrict__ nll, int Bp, int Cp, int C, int Lmax, int Tws) {
+  __shared__ float fin[64 * KS];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int L = label_len[b], Tb = seq_len[b], S = 2 * L + 1;
+  const int blank = C - 1;
+  const int* lab = labels + (size_t)b * Lmax;
+
+  int ext[KS];
+  bool act[KS], skip[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const int s = lane * KS + i;
+    act[i] = s < S;
+    ext[i] = (act[i] && (s & 1)) ? lab[s >> 1] : blank;
+  }
+  const size_t rstride = (size_t)Bp * Cp;               // logits row stride between frames
+  const float* lg = logits + (size_t)b * Cp;
+  const float* lz = logz + b;
+  auto emit = [&](int t, float (&e)[KS]) {
+    const float z = lz[(size_t)t * Bp];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) e[i] = act[i] ? lg[(size_t)t * rstride + ext[i]] - z : NEG;
+  };
+  float* ws = (w == 0 ? alpha : beta) + (size_t)b * Tws * KS * 64;
+  auto store = [&](int t, const float (&a)[KS]) {
+#pragma unroll
+    for (int i = 0; i < KS; ++i) ws[((size_t)t * KS + i) * 64 + lane] = a[i];
+  };
+
+  if (w == 0) {
+    // ---------------- alpha, forward in time
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int s = lane * KS + i;
+      const int e2 = (s >= 2 && (s & 1)) ? lab[(s >> 1) - 1] : blank;   // l'_{s-2}
+      skip[i] = act[i] && s >= 2 && ext[i] != blank && ext[i] != e2;
+    }
+    float a[KS], e[4][KS];
+    emit(0, e[0]);
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int s = lane * KS + i;
+      a[i] = (s < 2 && act[i]) ? e[0][i] : NEG;
+    }
+    store(0, a);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (1 + k < Tb) emit(1 + k, e[k]);
+    for (int t0 = 1; t0 < Tb; t0 += 4) {
+      float en[4][KS];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t0 + 4 + k < Tb) emit(t0 + 4 + k, en[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = t0 + k;
+        if (t < Tb) {
+          // neighbours from the previous lane
+          float p1 = __shfl_up(a[KS - 1], 1);
+          float p2 = (KS >= 2) ? __shfl_up(a[KS >= 2 ? KS - 2 : 0], 1) : __shfl_up(a[0], 2);
+          if (lane == 0) { p1 = NEG; p2 = NEG; }
+          if (KS == 1 && lane == 1) p2 = NEG;
+          float na[KS];
+#pragma unroll
+          for (int i = 0; i < KS; ++i) {
+            const float x1 = (i >= 1) ? a[i - 1] : p1;
+            const float x2 = (i >= 2) ? a[i - 2] : (i == 1 ? p1 : p2);
+            // note: for i == 1 the s-2 neighbour is the previous lane's LAST state (p1) only when KS == 1 is
+            // excluded; with KS >= 2 state s-2 of i==1 is previous lane's a[KS-1]
+            na[i] = e[k][i] + lse3(a[i], x1, skip[i] ? x2 : NEG);
+          }
+#pragma unroll
+          for (int i = 0; i < KS; ++i) a[i] = act[i] ? na[i] : NEG;
+          store(t, a);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < KS; ++i) e[k][i] = en[k][i];
+    }
+#pragma unroll
+    for (int i = 0; i < KS; ++i) fin[lane * KS + i] = a[i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave visible to itself
+    if (lane == 0) {
+      const float x = fin[S - 1];
+      const float y = S > 1 ? fin[S - 2] : NEG;
+      nll[b] = -lse3(x, y, NEG);
+    }
+  } else {
+    // ---------------- beta, backward in time (excludes the emission at t)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int s = lane * KS + i;
+      const int e2 = (s + 2 < S && (s & 1)) ? lab[(s >> 1) + 1] : blank;   // l'_{s+2}
+      skip[i] = (s + 2 < S) && e2 != blank && e2 != ext[i];
+    }
+    float bt[KS], e[4][KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int s = lane * KS + i;
+      bt[i] = (act[i] && (s == S - 1 || s == S - 2)) ? 0.f : NEG;
+    }
+    store(Tb - 1, bt);
+    // e[k] holds the emission of frame (t+1) for the k-th step of a group
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (Tb - 1 - k >= 1) emit(Tb - 1 - k, e[k]);
+    for (int t0 = Tb - 2; t0 >= 0; t0 -= 4) {
+      float en[4][KS];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t0 - 4 - k + 1 >= 1) emit(t0 - 4 - k + 1, en[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = t0 - k;
+        if (t >= 0) {
+          float bb[KS];
+#pragma unroll
+          for (int i = 0; i < KS; ++i) bb[i] = act[i] ? bt[i] + e[k][i] : NEG;
+          float n1 = __shfl_down(bb[0], 1);
+          float n2 = (KS >= 2) ? __shfl_down(bb[KS >= 2 ? 1 : 0], 1) : __shfl_down(bb[0], 2);
+          if (lane == 63) { n1 = NEG; n2 = NEG; }
+          if (KS == 1 && lane == 62) n2 = NEG;
+          float nb[KS];
+#pragma unroll
+          for (int i = 0; i < KS; ++i) {
+            const float x1 = (i + 1 < KS) ? bb[i + 1 < KS ? i + 1 : 0] : n1;
+            const float x2 = (i + 2 < KS) ? bb[i + 2 < KS ? i + 2 : 0] : (i + 1 < KS ? n1 : n2);
+            nb[i] = lse3(bb[i], x1, skip[i] ? x2 : NEG);
+          }
+#pragma unroll
+          for (int i = 0; i < KS; ++i) bt[i] = act[i] ? nb[i] : NEG;
+          store(t, bt);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < KS; ++i) e[k][i] = en[k][i];
+    }
+  }
+}
+
+void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,
+                           const int* label_len, const int* seq_len, float* alpha, float* beta, float* nll,
+                           hipStream_t st) {
+#define NASR_AB(K)                                                                                              \
+  hipLaunchKernelGGL((ctc_alpha_beta_kernel<K>), dim3(d.B), dim3(128), 0, st, logits, logz, labels, label_len, \
+                     seq_len, alpha, beta, nll, d.Bp, d.Cp, d.C, d.Lmax, d.Tws)
+  switch (d.KS) {
+    case 1: NASR_AB(1); break;
+    case 2: NASR_AB(2); break;
+    case 3: NASR_AB(3); break;
+    case 4: NASR_AB(4); break;
+    case 5: NASR_AB(5); break;
+    case 6: NASR_AB(6); break;
+    case 7: NASR_AB(7); break;
+    case 8: NASR_AB(8); break;
+    case 9: case 10: case 11: case 12: NASR_AB(12); break;
+    default: NASR_AB(16); break;
+  }
+#undef NASR_AB
+}
+
+// ------------------------------------------------------------------ (3) gradient, in place over the logits
+__global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logits, const float* __restrict__ logz,
+                                                       const int* __restrict__ labels,
+                                                       const int* __restrict__ label_len,
+                                                       const int* __restrict__ seq_len,
+                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                       const float* __restrict__ nll, float scale, int Tp, int B,
+                                                       int Bp, int C, int Cp, int Lmax, int KS, int Tws) {
+  extern __shared__ __attribute__((aligned(16))) float bins_all[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + wv;
+  if (row >= Tp * Bp) return;
+  const int t = row / Bp, b = row % Bp;
+  float* x = logits + (size_t)row * Cp;
+  if (b >= B || t >= seq_len[b]) {
+    for (int c = lane; c < Cp; c += 64) x[c] = 0.f;
+    return;
+  }
+  float* bins = bins_all + (size_t)wv * Cp;
+  for (int c = lane; c < Cp; c += 64) bins[c] = 0.f;
+  const int L = label_len[b], S = 2 * L + 1;
+  const float logp = -nll[b];
+  const int* lab = labels + (size_t)b * Lmax;
+  const float* al = alpha + ((size_t)b * Tws + t) * KS * 64;
+  const float* be = beta + ((size_t)b * Tws + t) * KS * 64;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  for (int i = 0; i < KS; ++i) {
+    const int s = lane * KS + i;
+    if (s < S) {
+      const int k = (s & 1) ? lab[s >> 1] : C - 1;
+      const float wgt = __expf(al[i * 64 + lane] + be[i * 64 + lane] - logp);
+      atomicAdd(&bins[k], wgt);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const float z = logz[row];
+  for (int c = lane; c < Cp; c += 64) {
+    float g = 0.f;
+    if (c < C) g = (__expf(x[c] - z) - bins[c]) * scale;
+    x[c] = g;
+  }
+}
+
+void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* labels, const int* label_len,
+                     const int* seq_len, const float* alpha, const float* beta, const float* nll, float scale,
+                     hipStream_t st) {
+  const int rows = d.Tp * d.Bp;
+  const int rpb = d.Cp <= 2048 ? 4 : 1;
+  hipLaunchKernelGGL(ctc_grad_kernel, dim3((rows + rpb - 1) / rpb), dim3(64 * rpb), (size_t)rpb * d.Cp * 4, st, logits,
+                     logz, labels, label_len, seq_len, alpha, beta, nll, scale, d.Tp, d.B, d.Bp, d.C, d.Cp, d.Lmax, d.KS,
+                     d.Tws);
+}
+
+// mean of n floats (n small: the batch), fixed order
+__global__ void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += v[i];
+    *out = s / (float)n;
+  }
+}
+void launch_mean(const float* v, int n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, st, v, n, out);
+}
+
+// ------------------------------------------------------------------ greedy decode (A.6)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, const int* __restrict__ seq_len,
+                                                     int* __restrict__ am, int Tp, int B, int Bp, int C, int Cp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= Tp * Bp) return;
+  const int t = row / Bp, b = row % Bp;
+  if (b >= B || t >= seq_len[b]) return;
+  const float* x = logits + (size_t)row * Cp;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[c];
+    if (v > best) { best = v; bi = c; }   // strict >: lowest index wins inside a lane
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) am[row] = bi;
+}
+
+__global__ void collapse_kernel(const int* __restrict__ am, const int* __restrict__ seq_len, int* __restrict__ ids,
+                                int* __restrict__ lens, int Tp, int B, int Bp, int blank) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0, prev = -1;
+  const int Tb = seq_len[b];
+  for (int t = 0; t < Tb; ++t) {
+    const int k = am[t * Bp + b];
+    if (k != prev && k != blank) ids[(size_t)b * Tp + n++] = k;
+    prev = k;
+  }
+  lens[b] = n;
+}
+
+void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, int* argmax_ws, int* ids, int* lens,
+                   hipStream_t st) {
+  const int rows = d.Tp * d.Bp;
+  hipLaunchKernelGGL(argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, seq_len, argmax_ws, d.Tp, d.B, d.Bp,
+                     d.C, d.Cp);
+  hipLaunchKernelGGL(collapse_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, argmax_ws, seq_len, ids, lens, d.Tp, d.B,
+                     d.Bp, d.C - 1);
+}
+
+}  // namespace nasr

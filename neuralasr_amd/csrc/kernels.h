@@ -1,0 +1,72 @@
+// kernels.h — launch wrappers of the gfx950 kernels behind libnasr.so (internal, C++).
+// Data layout in HBM (all fp32, time-major, padded):
+//   rows   r = t*Bp + b           Bp = round_up(B,16)
+//   X0     [R][Fp]                Fp = round_up(F,32)
+//   gates  [R][D*N4]              N4 = 4*Hp, Hp = round_up(H,64); column d*N4 + 4*j + g (gate-interleaved)
+//   out,c  [R][D*Hp]
+//   logits [T'*Bp][Cp]            Cp = round_up(C,32)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nasr {
+
+// ---- GEMM (gemm.hip): C[M,N] = opA[M,K] * opB[K,N] (+bias[n]) on v_mfma_f32_32x32x2_f32 ----
+struct GemmDesc {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;          // K % 16 == 0, M % 4 == 0, N % 4 == 0
+  int lda, ldb, ldc;    // element strides (multiples of 4)
+  bool a_col;           // false: A(m,k) = A[row(m)*lda + k]      true: A(m,k) = A[row(k)*lda + m]
+  bool b_col;           // false: B(k,n) = B[k*ldb + n]           true: B(k,n) = B[n*ldb + k]
+  const int* a_map;     // logical->physical row of A (-1 = zero row); NULL: physical = logical + a_shift
+  int a_shift;          // row shift applied when a_map == NULL
+  int a_rows;           // physical rows of A (rows outside [0,a_rows) read as zero)
+  const int* c_map;     // logical->physical row of C (-1 = skip); NULL: identity
+  const float* bias;    // per-n bias or NULL
+  int split_k;          // >=1; >1 writes partial slabs to `slabs` and reduces them into C
+  float* slabs;         // workspace of split_k*M*N floats (only when split_k > 1)
+};
+void launch_gemm(const GemmDesc& g, hipStream_t st);
+int gemm_pick_split(int M, int N, int K);
+
+// ---- LSTM recurrence (lstm.hip) ----
+struct LstmDims {
+  int T, B, Bp, H, Hp, D;   // D directions
+};
+void launch_pack_feats(const float* feats_bm, float* X0, int B, int Bp, int T, int F, int Fp, hipStream_t st);
+// repack canonical U [Hp][N4] of every (layer,dir) into the forward / backward MFMA B-operand images
+void launch_repack_u(const float* U, float* Uf, float* Ub, int Hp, hipStream_t st);
+void launch_lstm_fwd_step(const LstmDims& dm, int s, const float* Uf, const float* hin, float* hout, float* gates,
+                          float* cbuf, float* out, const int* seq_len, float forget_bias, hipStream_t st);
+void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const float* dgin, float* dgout, float* gates,
+                          const float* cbuf, const float* dout, float* dcstate, const int* seq_len, hipStream_t st);
+
+// ---- CTC (ctc.hip) ----
+struct CtcDims {
+  int Tp;      // logit frames T'
+  int B, Bp, C, Cp, Lmax;
+  int KS;      // states per lane: ceil((2*Lmax+1)/64)
+  int Tws;     // time extent of the alpha/beta workspace (max seq_len)
+};
+void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, float* logz, hipStream_t st);
+void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,
+                           const int* label_len, const int* seq_len, float* alpha, float* beta, float* nll,
+                           hipStream_t st);
+// in place: logits -> d(mean nll)/dlogits
+void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* labels, const int* label_len,
+                     const int* seq_len, const float* alpha, const float* beta, const float* nll, float scale,
+                     hipStream_t st);
+void launch_mean(const float* v, int n, float* out, hipStream_t st);
+void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, int* argmax_ws, int* ids, int* lens,
+                   hipStream_t st);
+
+// ---- optimiser / reductions (optim.hip) ----
+void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr_t, float beta1, float beta2,
+                 float eps, float gscale, hipStream_t st);
+// out[n] = sum_r M[r*ld + n], deterministic two-stage; ws holds 32*N floats
+void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st);
+void launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, hipStream_t st);
+
+}  // namespace nasr

@@ -1,0 +1,977 @@
+// nasr_api.hip — the C ABI of include/nasr.h: context, HBM layout, TF<->internal parameter maps and
+// the orchestration of one training step on one GPU.  See include/nasr.h for the reference
+// interfaces each entry point replaces and DESIGN.md for the layout.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nasr.h"
+#include "kernels.h"
+
+using namespace nasr;
+
+namespace {
+
+std::string g_create_error;
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes, bool* grew) {
+    if (bytes <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8;  // head room: fewer re-allocations for ragged T
+    if (hipMalloc(&p, want) != hipSuccess) {
+      if (hipMalloc(&p, bytes) != hipSuccess) return false;
+      want = bytes;
+    }
+    cap = want;
+    if (grew) *grew = true;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct TensorInfo {
+  std::string name;
+  int64_t offset, rows, cols;
+};
+
+enum Phase { PH_PACK = 0, PH_XPROJ, PH_RECF, PH_PROJCTC, PH_PROJB, PH_RECB, PH_WGRAD, PH_ADAM, PH_COUNT };
+
+struct GraphKey {
+  int T, l, bwd;
+  bool operator<(const GraphKey& o) const {
+    if (T != o.T) return T < o.T;
+    if (l != o.l) return l < o.l;
+    return bwd < o.bwd;
+  }
+};
+
+}  // namespace
+
+struct nasr_ctx {
+  nasr_model_cfg cfg;
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // model dims
+  int F, Fp, H, Hp, N4, D, L, C, Cp, Pin, Pinp;
+  std::vector<int> Ip;                  // padded input width per layer
+  std::vector<int64_t> off_wx, off_bias;  // per layer
+  std::vector<int64_t> off_u;           // per (layer, dir)
+  int64_t off_w = 0, off_b = 0, np_int = 0;
+  std::vector<TensorInfo> tensors;
+  int64_t np_tf = 0;
+  std::vector<int32_t> tf2int;          // TF flat index -> internal flat index
+
+  float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *Uf = nullptr, *Ub = nullptr;
+  int64_t adam_step = 0;
+  float lr;
+
+  // resident batch
+  bool resident = false, have_grads = false, have_fwd = false;
+  int B = 0, Bp = 0, T = 0, Lmax = 0, Tp = 0, KS = 1;
+  int64_t frames = 0;
+  std::vector<int32_t> h_seq;
+
+  DevBuf feats_bm, X0, dout, hstate, dgstate, dcstate, logits, logz, alpha, beta, nll, loss, seq, labels, lablen,
+      rowmap, slabs, csws, amax, ids, lens, stage;
+  std::vector<DevBuf> gates, outb, cbuf;
+
+  // graphs
+  bool graph_mode = true;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  struct Span { int ph; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
+  int n_fwd_launch = 0, n_bwd_launch = 0;
+  nasr_phase_times last_times;
+
+  int fail(int code, const std::string& m) {
+    err = m;
+    return code;
+  }
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      return (h)->fail(NASR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+void drop_graphs(nasr_ctx* h) {
+  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  h->graphs.clear();
+}
+
+hipEvent_t next_event(nasr_ctx* h) {
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    h->ev_pool.push_back(e);
+  }
+  return h->ev_pool[h->ev_used++];
+}
+
+struct PhaseScope {
+  nasr_ctx* h;
+  int ph;
+  hipEvent_t a = nullptr;
+  PhaseScope(nasr_ctx* h_, int ph_) : h(h_), ph(ph_) {
+    if (h->profiling) {
+      a = next_event(h);
+      (void)hipEventRecord(a, h->st);
+    }
+  }
+  ~PhaseScope() {
+    if (h->profiling) {
+      hipEvent_t b = next_event(h);
+      (void)hipEventRecord(b, h->st);
+      h->spans.push_back({ph, a, b});
+    }
+  }
+};
+
+// ---- model layout ---------------------------------------------------------------------------
+int build_layout(nasr_ctx* h) {
+  const nasr_model_cfg& c = h->cfg;
+  h->F = c.feature_size;
+  h->H = c.hidden;
+  h->L = c.num_layers;
+  h->D = c.bidirectional ? 2 : 1;
+  h->C = c.num_classes;
+  h->Fp = rup(h->F, 32);
+  h->Hp = rup(h->H, 64);
+  h->N4 = 4 * h->Hp;
+  h->Cp = rup(h->C, 32);
+  const bool concat = c.bidirectional && c.merge == NASR_MERGE_CONCAT;
+  h->Pin = concat ? 2 * h->H : h->H;
+  h->Pinp = concat ? 2 * h->Hp : h->Hp;
+  const int D = h->D, Hp = h->Hp, N4 = h->N4, H = h->H;
+
+  int64_t off = 0;
+  h->Ip.resize(h->L);
+  h->off_wx.resize(h->L);
+  h->off_bias.resize(h->L);
+  h->off_u.resize((size_t)h->L * D);
+  for (int l = 0; l < h->L; ++l) {
+    h->Ip[l] = l == 0 ? h->Fp : D * Hp;
+    h->off_wx[l] = off;
+    off += (int64_t)h->Ip[l] * D * N4;
+    h->off_bias[l] = off;
+    off += (int64_t)D * N4;
+    for (int d = 0; d < D; ++d) {
+      h->off_u[(size_t)l * D + d] = off;
+      off += (int64_t)Hp * N4;
+    }
+  }
+  h->off_w = off;
+  off += (int64_t)h->Pinp * h->Cp;
+  h->off_b = off;
+  off += h->Cp;
+  h->np_int = off;  // every term is a multiple of 32
+  if (off >= (int64_t)1 << 31) return h->fail(NASR_ERR_ARG, "model too large for 32-bit parameter indexing");
+
+  // TF variable order + element map
+  h->tensors.clear();
+  int64_t tfo = 0;
+  auto add = [&](const std::string& n, int64_t r, int64_t cc) {
+    h->tensors.push_back({n, tfo, r, cc});
+    tfo += r * cc;
+  };
+  for (int l = 0; l < h->L; ++l) {
+    const int I = l == 0 ? h->F : D * H;
+    for (int d = 0; d < D; ++d) {
+      std::string pre = "l" + std::to_string(l) + "/";
+      if (D == 2) pre += d == 0 ? "fw/" : "bw/";
+      add(pre + "kernel", I + H, 4 * H);
+      add(pre + "bias", 4 * H, 1);
+    }
+  }
+  add("W", h->Pin, h->C);
+  add("b", h->C, 1);
+  h->np_tf = tfo;
+  h->tf2int.assign((size_t)tfo, 0);
+  size_t ti = 0;
+  for (int l = 0; l < h->L; ++l) {
+    const int I = l == 0 ? h->F : D * H;
+    for (int d = 0; d < D; ++d) {
+      const TensorInfo& tk = h->tensors[ti++];
+      for (int r = 0; r < I + H; ++r) {
+        for (int cc = 0; cc < 4 * H; ++cc) {
+          const int g = cc / H, j = cc % H;
+          int64_t dst;
+          if (r < I) {
+            int ir = r;
+            if (l > 0 && D == 2 && r >= H) ir = Hp + (r - H);
+            dst = h->off_wx[l] + (int64_t)ir * D * N4 + d * N4 + 4 * j + g;
+          } else {
+            dst = h->off_u[(size_t)l * D + d] + (int64_t)(r - I) * N4 + 4 * j + g;
+          }
+          h->tf2int[(size_t)(tk.offset + (int64_t)r * 4 * H + cc)] = (int32_t)dst;
+        }
+      }
+      const TensorInfo& tb = h->tensors[ti++];
+      for (int cc = 0; cc < 4 * H; ++cc) {
+        const int g = cc / H, j = cc % H;
+        h->tf2int[(size_t)(tb.offset + cc)] = (int32_t)(h->off_bias[l] + d * N4 + 4 * j + g);
+      }
+    }
+  }
+  {
+    const TensorInfo& tw = h->tensors[ti++];
+    for (int r = 0; r < h->Pin; ++r) {
+      int ir = r;
+      if (concat && r >= H) ir = Hp + (r - H);
+      for (int cc = 0; cc < h->C; ++cc)
+        h->tf2int[(size_t)(tw.offset + (int64_t)r * h->C + cc)] = (int32_t)(h->off_w + (int64_t)ir * h->Cp + cc);
+    }
+    const TensorInfo& tb = h->tensors[ti++];
+    for (int cc = 0; cc < h->C; ++cc) h->tf2int[(size_t)(tb.offset + cc)] = (int32_t)(h->off_b + cc);
+  }
+  return NASR_OK;
+}
+
+int repack(nasr_ctx* h) {
+  for (int l = 0; l < h->L; ++l)
+    for (int d = 0; d < h->D; ++d) {
+      const size_t k = (size_t)l * h->D + d;
+      const size_t o = k * (size_t)h->Hp * h->N4;
+      launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
+    }
+  HIPCHK(h, hipGetLastError());
+  return NASR_OK;
+}
+
+int scatter_to_device(nasr_ctx* h, const float* tf_flat, float* dev) {
+  std::vector<float> host((size_t)h->np_int, 0.f);
+  for (int64_t i = 0; i < h->np_tf; ++i) host[(size_t)h->tf2int[(size_t)i]] = tf_flat[i];
+  HIPCHK(h, hipMemcpyAsync(dev, host.data(), (size_t)h->np_int * 4, hipMemcpyHostToDevice, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return NASR_OK;
+}
+
+int gather_from_device(nasr_ctx* h, const float* dev, float* tf_flat) {
+  std::vector<float> host((size_t)h->np_int);
+  HIPCHK(h, hipMemcpyAsync(host.data(), dev, (size_t)h->np_int * 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  for (int64_t i = 0; i < h->np_tf; ++i) tf_flat[i] = host[(size_t)h->tf2int[(size_t)i]];
+  return NASR_OK;
+}
+
+// ---- batch buffers --------------------------------------------------------------------------
+int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
+  const int Bp = rup(B, 16);
+  const int Tp = nasr_logit_frames(h, T);
+  const size_t R = (size_t)T * Bp;
+  const int D = h->D, Hp = h->Hp, N4 = h->N4;
+  const int KS = std::max(1, (2 * std::max(Lmax, 0) + 1 + 63) / 64);
+  if (KS > 16) return h->fail(NASR_ERR_ARG, "label length > 511 not supported by the CTC lattice kernel");
+  bool grew = false;
+  bool ok = true;
+  ok &= h->feats_bm.ensure((size_t)B * T * h->F * 4, &grew);
+  ok &= h->X0.ensure(R * h->Fp * 4, &grew);
+  ok &= h->dout.ensure(R * D * Hp * 4, &grew);
+  ok &= h->hstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
+  ok &= h->dgstate.ensure((size_t)2 * D * Bp * N4 * 4, &grew);
+  ok &= h->dcstate.ensure((size_t)D * Bp * Hp * 4, &grew);
+  ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
+  ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
+  const int KSa = KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations
+  ok &= h->alpha.ensure((size_t)B * T * KSa * 64 * 4, &grew);
+  ok &= h->beta.ensure((size_t)B * T * KSa * 64 * 4, &grew);
+  ok &= h->nll.ensure((size_t)Bp * 4, &grew);
+  ok &= h->loss.ensure(16, &grew);
+  ok &= h->seq.ensure((size_t)Bp * 4, &grew);
+  ok &= h->labels.ensure((size_t)std::max(1, B * std::max(Lmax, 1)) * 4, &grew);
+  ok &= h->lablen.ensure((size_t)Bp * 4, &grew);
+  ok &= h->rowmap.ensure((size_t)Tp * Bp * 4, &grew);
+  ok &= h->csws.ensure((size_t)32 * std::max(D * N4, h->Cp) * 4, &grew);
+  ok &= h->amax.ensure((size_t)Tp * Bp * 4, &grew);
+  ok &= h->ids.ensure((size_t)B * Tp * 4, &grew);
+  ok &= h->lens.ensure((size_t)Bp * 4, &grew);
+  for (int l = 0; l < h->L; ++l) {
+    ok &= h->gates[l].ensure(R * D * N4 * 4, &grew);
+    ok &= h->outb[l].ensure(R * D * Hp * 4, &grew);
+    ok &= h->cbuf[l].ensure(R * D * Hp * 4, &grew);
+  }
+  if (!ok) return h->fail(NASR_ERR_HIP, "hipMalloc failed while sizing batch buffers");
+  if (grew || Bp != h->Bp) drop_graphs(h);
+  h->B = B; h->Bp = Bp; h->T = T; h->Lmax = Lmax; h->Tp = Tp; h->KS = KSa;
+  return NASR_OK;
+}
+
+int validate_batch(nasr_ctx* h, const int32_t* seq_len, const int32_t* labels, const int32_t* label_len, int B, int T,
+                   int Lmax) {
+  if (B < 1 || B > 64) return h->fail(NASR_ERR_ARG, "per-GPU batch must be in [1,64]");
+  if (T < 1) return h->fail(NASR_ERR_ARG, "T must be >= 1");
+  for (int b = 0; b < B; ++b) {
+    if (seq_len[b] < 1 || seq_len[b] > T)
+      return h->fail(NASR_ERR_ARG, "seq_len[" + std::to_string(b) + "] out of [1,T]");
+    if (!labels) continue;
+    const int L = label_len[b];
+    if (L < 0 || L > Lmax) return h->fail(NASR_ERR_ARG, "label_len[" + std::to_string(b) + "] out of [0,Lmax]");
+    int rep = 0;
+    for (int i = 0; i < L; ++i) {
+      const int v = labels[(size_t)b * Lmax + i];
+      if (v < 0 || v >= h->C - 1)
+        return h->fail(NASR_ERR_ARG, "label id out of [0, num_classes-2] (blank = num_classes-1 is not a label)");
+      if (i > 0 && v == labels[(size_t)b * Lmax + i - 1]) ++rep;
+    }
+    if (L + rep > seq_len[b])
+      return h->fail(NASR_ERR_INFEASIBLE, "Not enough time for target transition sequence (required: " +
+                                              std::to_string(L + rep) + ", available: " + std::to_string(seq_len[b]) +
+                                              ") in sequence " + std::to_string(b));
+  }
+  return NASR_OK;
+}
+
+int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_t* labels, const int32_t* label_len,
+           int B, int T, int Lmax) {
+  if (!feats || !seq_len) return h->fail(NASR_ERR_ARG, "null input buffer");
+  if (labels && !label_len) return h->fail(NASR_ERR_ARG, "labels without label_len");
+  int rc = validate_batch(h, seq_len, labels, label_len, B, T, Lmax);
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  rc = ensure_shape(h, B, T, labels ? Lmax : 0);
+  if (rc) return rc;
+  const int Bp = h->Bp;
+  h->ev_used = 0;
+  h->spans.clear();
+  if (h->profiling) (void)hipEventRecord(h->ev_total_a, h->st);
+  h->h_seq.assign((size_t)Bp, 0);
+  h->frames = 0;
+  for (int b = 0; b < B; ++b) {
+    h->h_seq[b] = seq_len[b];
+    h->frames += seq_len[b];
+  }
+  {
+    PhaseScope ps(h, PH_PACK);
+    HIPCHK(h, hipMemcpyAsync(h->feats_bm.p, feats, (size_t)B * T * h->F * 4, hipMemcpyHostToDevice, h->st));
+    HIPCHK(h, hipMemcpyAsync(h->seq.p, h->h_seq.data(), (size_t)Bp * 4, hipMemcpyHostToDevice, h->st));
+    if (labels) {
+      std::vector<int32_t> ll((size_t)Bp, 0);
+      for (int b = 0; b < B; ++b) ll[b] = label_len[b];
+      if (Lmax > 0)
+        HIPCHK(h, hipMemcpyAsync(h->labels.p, labels, (size_t)B * Lmax * 4, hipMemcpyHostToDevice, h->st));
+      HIPCHK(h, hipMemcpyAsync(h->lablen.p, ll.data(), (size_t)Bp * 4, hipMemcpyHostToDevice, h->st));
+      HIPCHK(h, hipStreamSynchronize(h->st));  // ll is a stack-lifetime staging vector
+    }
+    if (h->cfg.merge == NASR_MERGE_STACK_RESHAPE && h->D == 2) {
+      // logits[t',b'] <- flat row q = b'*2T + t' of O = stack(fw,bw) [2,B,T,H];
+      // physical row index in the [(t*Bp+b)*2 + d][Hp] view of the last layer's output.
+      std::vector<int32_t> map((size_t)h->Tp * Bp, -1);
+      for (int tp = 0; tp < h->Tp; ++tp)
+        for (int bq = 0; bq < B; ++bq) {
+          const int64_t q = (int64_t)bq * 2 * T + tp;
+          const int d = (int)(q / ((int64_t)B * T));
+          const int64_t rem = q % ((int64_t)B * T);
+          const int b = (int)(rem / T), t = (int)(rem % T);
+          map[(size_t)tp * Bp + bq] = (t * Bp + b) * 2 + d;
+        }
+      HIPCHK(h, hipMemcpyAsync(h->rowmap.p, map.data(), map.size() * 4, hipMemcpyHostToDevice, h->st));
+      HIPCHK(h, hipStreamSynchronize(h->st));
+    }
+    launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->resident = true;
+  h->have_grads = false;
+  h->have_fwd = false;
+  return NASR_OK;
+}
+
+// ---- the per-timestep loops, optionally replayed from a hipGraph ---------------------------
+int run_steps(nasr_ctx* h, int l, bool bwd) {
+  const LstmDims dm{h->T, h->B, h->Bp, h->H, h->Hp, h->D};
+  const size_t sU = (size_t)l * h->D * h->Hp * h->N4;
+  const size_t hs = (size_t)h->D * h->Bp * h->Hp;   // one h-state image
+  const size_t gs = (size_t)h->D * h->Bp * h->N4;   // one dG-state image
+  auto body = [&]() {
+    if (!bwd) {
+      (void)hipMemsetAsync(h->hstate.p, 0, hs * 4, h->st);
+      for (int s = 0; s < h->T; ++s)
+        launch_lstm_fwd_step(dm, s, h->Uf + sU, h->hstate.as<float>() + (s & 1) * hs,
+                             h->hstate.as<float>() + ((s + 1) & 1) * hs, h->gates[l].as<float>(),
+                             h->cbuf[l].as<float>(), h->outb[l].as<float>(), h->seq.as<int>(), h->cfg.forget_bias,
+                             h->st);
+    } else {
+      (void)hipMemsetAsync(h->dgstate.p, 0, gs * 4, h->st);
+      (void)hipMemsetAsync(h->dcstate.p, 0, hs * 4, h->st);
+      int k = 0;
+      for (int s = h->T - 1; s >= 0; --s, ++k)
+        launch_lstm_bwd_step(dm, s, h->Ub + sU, h->dgstate.as<float>() + (k & 1) * gs,
+                             h->dgstate.as<float>() + ((k + 1) & 1) * gs, h->gates[l].as<float>(),
+                             h->cbuf[l].as<float>(), h->dout.as<float>(), h->dcstate.as<float>(), h->seq.as<int>(),
+                             h->st);
+    }
+  };
+  if (!h->graph_mode) {
+    body();
+    HIPCHK(h, hipGetLastError());
+    return NASR_OK;
+  }
+  const GraphKey key{h->T, l, bwd ? 1 : 0};
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    if (h->graphs.size() > 48) drop_graphs(h);
+    hipGraph_t g = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+    body();
+    HIPCHK(h, hipStreamEndCapture(h->st, &g));
+    hipGraphExec_t ex = nullptr;
+    HIPCHK(h, hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = h->graphs.emplace(key, ex).first;
+  }
+  HIPCHK(h, hipGraphLaunch(it->second, h->st));
+  return NASR_OK;
+}
+
+float* ensure_slabs(nasr_ctx* h, int split, int M, int N) {
+  if (split <= 1) return nullptr;
+  bool grew = false;
+  if (!h->slabs.ensure((size_t)split * M * N * 4, &grew)) return nullptr;
+  return h->slabs.as<float>();
+}
+
+int forward(nasr_ctx* h) {
+  if (!h->resident) return h->fail(NASR_ERR_STATE, "no resident batch: call nasr_upload_batch first");
+  const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp, N4 = h->N4;
+  const int R = T * Bp;
+  h->n_fwd_launch = 0;
+  for (int l = 0; l < h->L; ++l) {
+    {
+      PhaseScope ps(h, PH_XPROJ);
+      GemmDesc g{};
+      g.A = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
+      g.B = h->P + h->off_wx[l];
+      g.C = h->gates[l].as<float>();
+      g.M = R; g.N = D * N4; g.K = h->Ip[l];
+      g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
+      g.a_col = false; g.b_col = false; g.a_rows = R; g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+      launch_gemm(g, h->st);
+      HIPCHK(h, hipGetLastError());
+    }
+    {
+      PhaseScope ps(h, PH_RECF);
+      int rc = run_steps(h, l, false);
+      if (rc) return rc;
+      h->n_fwd_launch += T;
+    }
+  }
+  {
+    PhaseScope ps(h, PH_PROJCTC);
+    const bool sr = h->cfg.merge == NASR_MERGE_STACK_RESHAPE && D == 2;
+    GemmDesc g{};
+    g.A = h->outb[h->L - 1].as<float>();
+    g.B = h->P + h->off_w;
+    g.C = h->logits.as<float>();
+    g.M = h->Tp * Bp; g.N = h->Cp; g.K = h->Pinp;
+    g.lda = sr ? Hp : D * Hp; g.ldb = h->Cp; g.ldc = h->Cp;
+    g.a_map = sr ? h->rowmap.as<int>() : nullptr;
+    g.a_rows = sr ? 2 * R : R;
+    g.bias = h->P + h->off_b; g.split_k = 1;
+    launch_gemm(g, h->st);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->have_fwd = true;
+  return NASR_OK;
+}
+
+CtcDims ctc_dims(nasr_ctx* h) {
+  CtcDims d;
+  d.Tp = h->Tp; d.B = h->B; d.Bp = h->Bp; d.C = h->C; d.Cp = h->Cp; d.Lmax = std::max(h->Lmax, 1);
+  d.KS = h->KS; d.Tws = h->T;
+  return d;
+}
+
+int ctc_forward(nasr_ctx* h) {
+  PhaseScope ps(h, PH_PROJCTC);
+  const CtcDims d = ctc_dims(h);
+  launch_ctc_logz(d, h->logits.as<float>(), h->seq.as<int>(), h->logz.as<float>(), h->st);
+  launch_ctc_alpha_beta(d, h->logits.as<float>(), h->logz.as<float>(), h->labels.as<int>(), h->lablen.as<int>(),
+                        h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->nll.as<float>(), h->st);
+  launch_mean(h->nll.as<float>(), h->B, h->loss.as<float>(), h->st);
+  HIPCHK(h, hipGetLastError());
+  return NASR_OK;
+}
+
+int backward(nasr_ctx* h) {
+  const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp, N4 = h->N4;
+  const int R = T * Bp, Rp = h->Tp * Bp;
+  const bool sr = h->cfg.merge == NASR_MERGE_STACK_RESHAPE && D == 2;
+  {
+    PhaseScope ps(h, PH_PROJCTC);
+    const CtcDims d = ctc_dims(h);
+    launch_ctc_grad(d, h->logits.as<float>(), h->logz.as<float>(), h->labels.as<int>(), h->lablen.as<int>(),
+                    h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->nll.as<float>(),
+                    1.f / (float)h->B, h->st);
+    HIPCHK(h, hipGetLastError());
+  }
+  {
+    PhaseScope ps(h, PH_PROJB);
+    // dW = gather(out)^T dlogits
+    GemmDesc g{};
+    g.A = h->outb[h->L - 1].as<float>();
+    g.B = h->logits.as<float>();
+    g.C = h->G + h->off_w;
+    g.M = h->Pinp; g.N = h->Cp; g.K = Rp;
+    g.lda = sr ? Hp : D * Hp; g.ldb = h->Cp; g.ldc = h->Cp;
+    g.a_col = true; g.a_map = sr ? h->rowmap.as<int>() : nullptr; g.a_rows = sr ? 2 * R : R;
+    g.split_k = gemm_pick_split(g.M, g.N, g.K);
+    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+    if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+    launch_gemm(g, h->st);
+    launch_colsum(h->logits.as<float>(), Rp, h->Cp, h->Cp, h->G + h->off_b, h->csws.as<float>(), h->st);
+    // dOut_last = scatter(dlogits W^T)
+    GemmDesc x{};
+    x.A = h->logits.as<float>();
+    x.B = h->P + h->off_w;
+    x.C = h->dout.as<float>();
+    x.M = Rp; x.N = h->Pinp; x.K = h->Cp;
+    x.lda = h->Cp; x.ldb = h->Cp; x.ldc = sr ? Hp : D * Hp;
+    x.b_col = true; x.a_rows = Rp; x.c_map = sr ? h->rowmap.as<int>() : nullptr; x.split_k = 1;
+    launch_gemm(x, h->st);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->n_bwd_launch = 0;
+  for (int l = h->L - 1; l >= 0; --l) {
+    {
+      PhaseScope ps(h, PH_RECB);
+      int rc = run_steps(h, l, true);
+      if (rc) return rc;
+      h->n_bwd_launch += T;
+    }
+    PhaseScope ps(h, PH_WGRAD);
+    const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
+    float* dG = h->gates[l].as<float>();
+    {  // dWx = X^T dG
+      GemmDesc g{};
+      g.A = Xl; g.B = dG; g.C = h->G + h->off_wx[l];
+      g.M = h->Ip[l]; g.N = D * N4; g.K = R;
+      g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
+      g.a_col = true; g.a_rows = R;
+      g.split_k = gemm_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm(g, h->st);
+    }
+    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), h->st);
+    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
+      GemmDesc g{};
+      g.A = h->outb[l].as<float>() + d * Hp;
+      g.B = dG + d * N4;
+      g.C = h->G + h->off_u[(size_t)l * D + d];
+      g.M = Hp; g.N = N4; g.K = R;
+      g.lda = D * Hp; g.ldb = D * N4; g.ldc = N4;
+      g.a_col = true; g.a_shift = d == 0 ? -Bp : Bp; g.a_rows = R;
+      g.split_k = gemm_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm(g, h->st);
+    }
+    if (l > 0) {  // gradient wrt the layer input = the layer below's output
+      GemmDesc g{};
+      g.A = dG; g.B = h->P + h->off_wx[l]; g.C = h->dout.as<float>();
+      g.M = R; g.N = h->Ip[l]; g.K = D * N4;
+      g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp;
+      g.b_col = true; g.a_rows = R; g.split_k = 1;
+      launch_gemm(g, h->st);
+    }
+    HIPCHK(h, hipGetLastError());
+  }
+  h->have_grads = true;
+  h->have_fwd = false;  // activations were overwritten by dG
+  return NASR_OK;
+}
+
+int fetch_logits(nasr_ctx* h, float* logits_out) {
+  const size_t n = (size_t)h->Tp * h->Bp * h->Cp;
+  std::vector<float> host(n);
+  HIPCHK(h, hipMemcpyAsync(host.data(), h->logits.p, n * 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  for (int t = 0; t < h->Tp; ++t)
+    for (int b = 0; b < h->B; ++b)
+      memcpy(logits_out + ((size_t)t * h->B + b) * h->C, host.data() + ((size_t)t * h->Bp + b) * h->Cp,
+             (size_t)h->C * 4);
+  return NASR_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_handle* out) {
+  if (!cfg || !out) {
+    g_create_error = "nasr_create: null argument";
+    return NASR_ERR_ARG;
+  }
+  *out = nullptr;
+  if (cfg->feature_size < 1 || cfg->hidden < 1 || cfg->num_layers < 1 || cfg->num_classes < 2) {
+    g_create_error = "nasr_create: feature_size, hidden, num_layers must be >= 1 and num_classes >= 2";
+    return NASR_ERR_ARG;
+  }
+  if (cfg->bidirectional && cfg->merge != NASR_MERGE_STACK_RESHAPE && cfg->merge != NASR_MERGE_CONCAT) {
+    g_create_error = "nasr_create: bidirectional nets need merge = STACK_RESHAPE or CONCAT";
+    return NASR_ERR_ARG;
+  }
+  if (cfg->bidirectional && cfg->merge == NASR_MERGE_STACK_RESHAPE && cfg->num_layers != 1) {
+    g_create_error = "nasr_create: STACK_RESHAPE is the literal 1-layer BiLstmCTCNet; use CONCAT for stacks";
+    return NASR_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_create_error = "nasr_create: no HIP device visible (libnasr has no CPU fallback)";
+    return NASR_ERR_HIP;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    g_create_error = "nasr_create: device_id out of range";
+    return NASR_ERR_ARG;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+    g_create_error = "nasr_create: hipGetDeviceProperties failed";
+    return NASR_ERR_HIP;
+  }
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    g_create_error = std::string("nasr_create: device is ") + prop.gcnArchName + ", libnasr is built for gfx950 only";
+    return NASR_ERR_HIP;
+  }
+  nasr_ctx* h = new nasr_ctx();
+  h->cfg = *cfg;
+  if (!cfg->bidirectional) h->cfg.merge = NASR_MERGE_NONE;
+  h->device = device_id;
+  h->lr = cfg->learning_rate;
+  auto bail = [&](int code, const std::string& m) {
+    g_create_error = m;
+    nasr_destroy(h);
+    return code;
+  };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(NASR_ERR_HIP, "hipSetDevice failed");
+  if (stream) {
+    h->st = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess)
+      return bail(NASR_ERR_HIP, "hipStreamCreate failed");
+    h->own_stream = true;
+  }
+  if (build_layout(h) != NASR_OK) return bail(NASR_ERR_ARG, h->err);
+  const size_t nb = (size_t)h->np_int * 4;
+  const size_t ub = (size_t)h->L * h->D * h->Hp * h->N4 * 4;
+  if (hipMalloc(&h->P, nb) != hipSuccess || hipMalloc(&h->M, nb) != hipSuccess || hipMalloc(&h->V, nb) != hipSuccess ||
+      hipMalloc(&h->G, nb) != hipSuccess || hipMalloc(&h->Uf, ub) != hipSuccess || hipMalloc(&h->Ub, ub) != hipSuccess)
+    return bail(NASR_ERR_HIP, "hipMalloc of parameter buffers failed");
+  (void)hipMemsetAsync(h->P, 0, nb, h->st);
+  (void)hipMemsetAsync(h->M, 0, nb, h->st);
+  (void)hipMemsetAsync(h->V, 0, nb, h->st);
+  (void)hipMemsetAsync(h->G, 0, nb, h->st);
+  (void)hipMemsetAsync(h->Uf, 0, ub, h->st);
+  (void)hipMemsetAsync(h->Ub, 0, ub, h->st);
+  h->gates.resize(h->L);
+  h->outb.resize(h->L);
+  h->cbuf.resize(h->L);
+  (void)hipEventCreate(&h->ev_total_a);
+  (void)hipEventCreate(&h->ev_total_b);
+  memset(&h->last_times, 0, sizeof(h->last_times));
+  if (hipStreamSynchronize(h->st) != hipSuccess) return bail(NASR_ERR_HIP, "stream synchronize failed in create");
+  *out = h;
+  return NASR_OK;
+}
+
+int nasr_destroy(nasr_handle h) {
+  if (!h) return NASR_OK;
+  (void)hipSetDevice(h->device);
+  if (h->st) (void)hipStreamSynchronize(h->st);
+  drop_graphs(h);
+  for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub})
+    if (p) (void)hipFree(p);
+  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->dgstate, &h->dcstate, &h->logits, &h->logz,
+                    &h->alpha, &h->beta, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
+                    &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
+    b->release();
+  for (auto& b : h->gates) b.release();
+  for (auto& b : h->outb) b.release();
+  for (auto& b : h->cbuf) b.release();
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->ev_total_a) (void)hipEventDestroy(h->ev_total_a);
+  if (h->ev_total_b) (void)hipEventDestroy(h->ev_total_b);
+  if (h->own_stream && h->st) (void)hipStreamDestroy(h->st);
+  delete h;
+  return NASR_OK;
+}
+
+const char* nasr_last_error(nasr_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* nasr_backend(nasr_handle) { return "hip-gfx950"; }
+
+int nasr_synchronize(nasr_handle h) {
+  if (!h) return NASR_ERR_ARG;
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return NASR_OK;
+}
+
+int64_t nasr_param_count(nasr_handle h) { return h ? h->np_tf : -1; }
+int nasr_num_tensors(nasr_handle h) { return h ? (int)h->tensors.size() : -1; }
+
+int nasr_tensor_info(nasr_handle h, int idx, char name[64], int64_t* offset, int64_t* rows, int64_t* cols) {
+  if (!h) return NASR_ERR_ARG;
+  if (idx < 0 || idx >= (int)h->tensors.size()) return h->fail(NASR_ERR_ARG, "tensor index out of range");
+  const TensorInfo& t = h->tensors[idx];
+  if (name) {
+    strncpy(name, t.name.c_str(), 63);
+    name[63] = 0;
+  }
+  if (offset) *offset = t.offset;
+  if (rows) *rows = t.rows;
+  if (cols) *cols = t.cols;
+  return NASR_OK;
+}
+
+int nasr_set_params(nasr_handle h, const float* flat, int64_t n) {
+  if (!h || !flat) return NASR_ERR_ARG;
+  if (n != h->np_tf) return h->fail(NASR_ERR_ARG, "nasr_set_params: expected " + std::to_string(h->np_tf) + " floats");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = scatter_to_device(h, flat, h->P);
+  if (rc) return rc;
+  rc = repack(h);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return NASR_OK;
+}
+
+int nasr_get_params(nasr_handle h, float* flat, int64_t n) {
+  if (!h || !flat) return NASR_ERR_ARG;
+  if (n != h->np_tf) return h->fail(NASR_ERR_ARG, "nasr_get_params: wrong length");
+  HIPCHK(h, hipSetDevice(h->device));
+  return gather_from_device(h, h->P, flat);
+}
+
+int nasr_set_adam_state(nasr_handle h, const float* m, const float* v, int64_t n, int64_t step) {
+  if (!h || !m || !v) return NASR_ERR_ARG;
+  if (n != h->np_tf || step < 0) return h->fail(NASR_ERR_ARG, "nasr_set_adam_state: wrong length or negative step");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = scatter_to_device(h, m, h->M);
+  if (rc) return rc;
+  rc = scatter_to_device(h, v, h->V);
+  if (rc) return rc;
+  h->adam_step = step;
+  return NASR_OK;
+}
+
+int nasr_get_adam_state(nasr_handle h, float* m, float* v, int64_t n, int64_t* step) {
+  if (!h) return NASR_ERR_ARG;
+  if (n != h->np_tf) return h->fail(NASR_ERR_ARG, "nasr_get_adam_state: wrong length");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = NASR_OK;
+  if (m) rc = gather_from_device(h, h->M, m);
+  if (!rc && v) rc = gather_from_device(h, h->V, v);
+  if (step) *step = h->adam_step;
+  return rc;
+}
+
+int nasr_set_learning_rate(nasr_handle h, float lr) {
+  if (!h) return NASR_ERR_ARG;
+  h->lr = lr;
+  return NASR_OK;
+}
+
+int nasr_logit_frames(nasr_handle h, int T) {
+  if (!h) return NASR_ERR_ARG;
+  return (h->cfg.bidirectional && h->cfg.merge == NASR_MERGE_STACK_RESHAPE) ? 2 * T : T;
+}
+
+int nasr_upload_batch(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                      const int32_t* label_len, int B, int T, int Lmax) {
+  if (!h) return NASR_ERR_ARG;
+  return upload(h, feats, seq_len, labels, label_len, B, T, Lmax);
+}
+
+int nasr_compute_grads(nasr_handle h) {
+  if (!h) return NASR_ERR_ARG;
+  if (!h->resident) return h->fail(NASR_ERR_STATE, "no resident batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->profiling && h->spans.size() > 1) {  // a fresh timing window per step when the batch stays resident
+    h->ev_used = 0;
+    h->spans.clear();
+    (void)hipEventRecord(h->ev_total_a, h->st);
+  }
+  int rc = forward(h);
+  if (rc) return rc;
+  rc = ctc_forward(h);
+  if (rc) return rc;
+  return backward(h);
+}
+
+void* nasr_grad_device_ptr(nasr_handle h) { return h ? h->G : nullptr; }
+int64_t nasr_grad_device_count(nasr_handle h) { return h ? h->np_int : -1; }
+
+int nasr_apply_adam(nasr_handle h, float grad_scale) {
+  if (!h) return NASR_ERR_ARG;
+  if (!h->have_grads) return h->fail(NASR_ERR_STATE, "nasr_apply_adam without gradients");
+  HIPCHK(h, hipSetDevice(h->device));
+  {
+    PhaseScope ps(h, PH_ADAM);
+    h->adam_step += 1;
+    const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
+    const double lr_t = (double)h->lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_step)) /
+                        (1.0 - std::pow(b1, (double)h->adam_step));
+    launch_adam(h->P, h->M, h->V, h->G, h->np_int, (float)lr_t, h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, grad_scale,
+                h->st);
+    int rc = repack(h);
+    if (rc) return rc;
+  }
+  if (h->profiling) (void)hipEventRecord(h->ev_total_b, h->st);
+  h->have_grads = false;
+  return NASR_OK;
+}
+
+int nasr_get_loss(nasr_handle h, float* loss_out) {
+  if (!h || !loss_out) return NASR_ERR_ARG;
+  HIPCHK(h, hipMemcpyAsync(loss_out, h->loss.p, 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return NASR_OK;
+}
+
+int nasr_resident_frames(nasr_handle h, int64_t* frames) {
+  if (!h || !frames) return NASR_ERR_ARG;
+  *frames = h->resident ? h->frames : 0;
+  return NASR_OK;
+}
+
+int nasr_train_step(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                    const int32_t* label_len, int B, int T, int Lmax, float* loss_out) {
+  if (!h) return NASR_ERR_ARG;
+  if (!labels) return h->fail(NASR_ERR_ARG, "nasr_train_step needs labels");
+  int rc = upload(h, feats, seq_len, labels, label_len, B, T, Lmax);
+  if (rc) return rc;
+  rc = nasr_compute_grads(h);
+  if (rc) return rc;
+  rc = nasr_apply_adam(h, 1.f);
+  if (rc) return rc;
+  if (loss_out) return nasr_get_loss(h, loss_out);
+  return NASR_OK;
+}
+
+int nasr_forward(nasr_handle h, const float* feats, const int32_t* seq_len, int B, int T, float* logits_out) {
+  if (!h) return NASR_ERR_ARG;
+  int rc = upload(h, feats, seq_len, nullptr, nullptr, B, T, 0);
+  if (rc) return rc;
+  rc = forward(h);
+  if (rc) return rc;
+  if (logits_out) return fetch_logits(h, logits_out);
+  return nasr_synchronize(h);
+}
+
+int nasr_loss(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+              const int32_t* label_len, int B, int T, int Lmax, float* loss_out, float* nll_out) {
+  if (!h) return NASR_ERR_ARG;
+  if (!labels) return h->fail(NASR_ERR_ARG, "nasr_loss needs labels");
+  int rc = upload(h, feats, seq_len, labels, label_len, B, T, Lmax);
+  if (rc) return rc;
+  rc = forward(h);
+  if (rc) return rc;
+  rc = ctc_forward(h);
+  if (rc) return rc;
+  if (nll_out) HIPCHK(h, hipMemcpyAsync(nll_out, h->nll.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
+  if (loss_out) return nasr_get_loss(h, loss_out);
+  return nasr_synchronize(h);
+}
+
+int nasr_loss_and_grads(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                        const int32_t* label_len, int B, int T, int Lmax, float* loss_out, float* nll_out,
+                        float* flat_grads_out) {
+  if (!h) return NASR_ERR_ARG;
+  if (!labels) return h->fail(NASR_ERR_ARG, "nasr_loss_and_grads needs labels");
+  int rc = upload(h, feats, seq_len, labels, label_len, B, T, Lmax);
+  if (rc) return rc;
+  rc = nasr_compute_grads(h);
+  if (rc) return rc;
+  if (nll_out) HIPCHK(h, hipMemcpyAsync(nll_out, h->nll.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
+  if (loss_out) {
+    rc = nasr_get_loss(h, loss_out);
+    if (rc) return rc;
+  }
+  if (flat_grads_out) return gather_from_device(h, h->G, flat_grads_out);
+  return nasr_synchronize(h);
+}
+
+int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len, int B, int T, int32_t* ids_out,
+                       int32_t* lens_out) {
+  if (!h || !ids_out || !lens_out) return NASR_ERR_ARG;
+  int rc = upload(h, feats, seq_len, nullptr, nullptr, B, T, 0);
+  if (rc) return rc;
+  rc = forward(h);
+  if (rc) return rc;
+  const CtcDims d = ctc_dims(h);
+  launch_greedy(d, h->logits.as<float>(), h->seq.as<int>(), h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
+                h->st);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(lens_out, h->lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(ids_out, h->ids.p, (size_t)B * h->Tp * 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return NASR_OK;
+}
+
+int nasr_set_profiling(nasr_handle h, int enabled) {
+  if (!h) return NASR_ERR_ARG;
+  h->profiling = enabled != 0;
+  h->ev_used = 0;
+  h->spans.clear();
+  return NASR_OK;
+}
+
+int nasr_get_phase_times(nasr_handle h, nasr_phase_times* out) {
+  if (!h || !out) return NASR_ERR_ARG;
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  float acc[PH_COUNT] = {0};
+  for (const auto& s : h->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) acc[s.ph] += ms;
+  }
+  nasr_phase_times t;
+  memset(&t, 0, sizeof(t));
+  t.pack_ms = acc[PH_PACK]; t.xproj_ms = acc[PH_XPROJ]; t.rec_fwd_ms = acc[PH_RECF]; t.proj_ctc_ms = acc[PH_PROJCTC];
+  t.proj_bwd_ms = acc[PH_PROJB]; t.rec_bwd_ms = acc[PH_RECB]; t.wgrad_ms = acc[PH_WGRAD]; t.adam_ms = acc[PH_ADAM];
+  float tot = 0.f;
+  if (h->profiling && hipEventElapsedTime(&tot, h->ev_total_a, h->ev_total_b) == hipSuccess) t.total_ms = tot;
+  t.rec_fwd_launches = h->n_fwd_launch;
+  t.rec_bwd_launches = h->n_bwd_launch;
+  *out = t;
+  return NASR_OK;
+}
+
+int nasr_set_graph_mode(nasr_handle h, int enabled) {
+  if (!h) return NASR_ERR_ARG;
+  h->graph_mode = enabled != 0;
+  if (!h->graph_mode) drop_graphs(h);
+  return NASR_OK;
+}
+
+}  // extern "C"

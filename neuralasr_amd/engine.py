@@ -1,0 +1,204 @@
+"""Engine: NumPy-in / NumPy-out wrapper over one libnasr handle (= one GPU).  This is the thin layer the
+`Network` plugin classes (neuralasr_amd/networks) and bench.py sit on; all arithmetic happens in the HIP
+library behind include/nasr.h."""
+import ctypes
+from ctypes import POINTER, byref, c_char, c_float, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+from . import _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(POINTER(c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(POINTER(c_int32))
+
+
+class Engine:
+    def __init__(self, feature_size, hidden, num_layers, bidirectional, merge, num_classes, forget_bias=1.0,
+                 learning_rate=1e-4, beta1=0.9, beta2=0.999, epsilon=1e-8, device_id=0, stream=None):
+        self.lib = _lib.load()
+        merge_id = _lib.MERGE_BY_NAME[merge] if isinstance(merge, str) else int(merge)
+        self.cfg = _lib.ModelCfg(int(feature_size), int(hidden), int(num_layers), int(bool(bidirectional)), merge_id,
+                                 int(num_classes), float(forget_bias), float(learning_rate), float(beta1),
+                                 float(beta2), float(epsilon))
+        self.h = c_void_p()
+        rc = self.lib.nasr_create(byref(self.cfg), int(device_id), c_void_p(stream) if stream else None, byref(self.h))
+        if rc != 0:
+            msg = self.lib.nasr_last_error(None)
+            self.h = None
+            raise _lib.NasrError(rc, msg.decode() if msg else 'nasr_create failed')
+        self.num_classes = int(num_classes)
+        self.param_count = int(self.lib.nasr_param_count(self.h))
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.nasr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _lib.check(self.lib, self.h, rc)
+
+    @property
+    def backend(self):
+        return self.lib.nasr_backend(self.h).decode()
+
+    def synchronize(self):
+        self._ck(self.lib.nasr_synchronize(self.h))
+
+    # ------------------------------------------------------------------ parameters
+    def tensors(self):
+        out = []
+        for i in range(self.lib.nasr_num_tensors(self.h)):
+            name = (c_char * 64)()
+            off, r, c = c_int64(), c_int64(), c_int64()
+            self._ck(self.lib.nasr_tensor_info(self.h, i, byref(name), byref(off), byref(r), byref(c)))
+            out.append((name.value.decode(), off.value, r.value, c.value))
+        return out
+
+    def set_params(self, flat):
+        flat = _f32(flat).ravel()
+        self._ck(self.lib.nasr_set_params(self.h, _fp(flat), flat.size))
+
+    def get_params(self):
+        flat = np.empty(self.param_count, np.float32)
+        self._ck(self.lib.nasr_get_params(self.h, _fp(flat), flat.size))
+        return flat
+
+    def set_adam_state(self, m, v, step):
+        m, v = _f32(m).ravel(), _f32(v).ravel()
+        self._ck(self.lib.nasr_set_adam_state(self.h, _fp(m), _fp(v), m.size, int(step)))
+
+    def get_adam_state(self):
+        m = np.empty(self.param_count, np.float32)
+        v = np.empty(self.param_count, np.float32)
+        step = c_int64()
+        self._ck(self.lib.nasr_get_adam_state(self.h, _fp(m), _fp(v), m.size, byref(step)))
+        return m, v, step.value
+
+    def set_learning_rate(self, lr):
+        self._ck(self.lib.nasr_set_learning_rate(self.h, float(lr)))
+
+    # ------------------------------------------------------------------ host-buffer entry points
+    @staticmethod
+    def _batch(feats, seq_len, labels=None, label_len=None):
+        feats = _f32(feats)
+        assert feats.ndim == 3, 'features must be [B,T,F]'
+        B, T, _ = feats.shape
+        seq = _i32(np.asarray([int(x) for x in seq_len])).ravel()
+        assert seq.size == B
+        if labels is None:
+            return feats, seq, None, None, B, T, 0
+        labels = _i32(labels)
+        if labels.ndim == 1:
+            labels = labels.reshape(B, -1)
+        ll = _i32(np.asarray([int(x) for x in label_len])).ravel()
+        assert labels.shape[0] == B and ll.size == B
+        return feats, seq, labels, ll, B, T, labels.shape[1]
+
+    def logit_frames(self, T):
+        return int(self.lib.nasr_logit_frames(self.h, int(T)))
+
+    def forward(self, feats, seq_len):
+        feats, seq, _, _, B, T, _ = self._batch(feats, seq_len)
+        if feats.shape[2] != self.cfg.feature_size:
+            raise ValueError(f'feature size {feats.shape[2]} != configured {self.cfg.feature_size}')
+        out = np.empty((self.logit_frames(T), B, self.num_classes), np.float32)
+        self._ck(self.lib.nasr_forward(self.h, _fp(feats), _ip(seq), B, T, _fp(out)))
+        return out
+
+    def loss(self, feats, seq_len, labels, label_len):
+        feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
+        loss = c_float()
+        nll = np.empty(B, np.float32)
+        self._ck(self.lib.nasr_loss(self.h, _fp(feats), _ip(seq), _ip(labels), _ip(ll), B, T, Lmax, byref(loss),
+                                    _fp(nll)))
+        return float(loss.value), nll
+
+    def loss_and_grads(self, feats, seq_len, labels, label_len):
+        feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
+        loss = c_float()
+        nll = np.empty(B, np.float32)
+        grads = np.empty(self.param_count, np.float32)
+        self._ck(self.lib.nasr_loss_and_grads(self.h, _fp(feats), _ip(seq), _ip(labels), _ip(ll), B, T, Lmax,
+                                              byref(loss), _fp(nll), _fp(grads)))
+        return float(loss.value), nll, grads
+
+    def train_step(self, feats, seq_len, labels, label_len):
+        feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
+        loss = c_float()
+        self._ck(self.lib.nasr_train_step(self.h, _fp(feats), _ip(seq), _ip(labels), _ip(ll), B, T, Lmax, byref(loss)))
+        return float(loss.value)
+
+    def greedy_decode(self, feats, seq_len):
+        feats, seq, _, _, B, T, _ = self._batch(feats, seq_len)
+        Tp = self.logit_frames(T)
+        ids = np.zeros((B, Tp), np.int32)
+        lens = np.zeros(B, np.int32)
+        self._ck(self.lib.nasr_greedy_decode(self.h, _fp(feats), _ip(seq), B, T, _ip(ids), _ip(lens)))
+        return [ids[b, :lens[b]].tolist() for b in range(B)]
+
+    # ------------------------------------------------------------------ resident-batch / data-parallel pieces
+    def upload_batch(self, feats, seq_len, labels, label_len):
+        feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
+        self._ck(self.lib.nasr_upload_batch(self.h, _fp(feats), _ip(seq), _ip(labels), _ip(ll), B, T, Lmax))
+
+    def compute_grads(self):
+        self._ck(self.lib.nasr_compute_grads(self.h))
+
+    def apply_adam(self, grad_scale=1.0):
+        self._ck(self.lib.nasr_apply_adam(self.h, float(grad_scale)))
+
+    def get_loss(self):
+        loss = c_float()
+        self._ck(self.lib.nasr_get_loss(self.h, byref(loss)))
+        return float(loss.value)
+
+    def resident_frames(self):
+        n = c_int64()
+        self._ck(self.lib.nasr_resident_frames(self.h, byref(n)))
+        return n.value
+
+    def grad_device_ptr(self):
+        return int(self.lib.nasr_grad_device_ptr(self.h)), int(self.lib.nasr_grad_device_count(self.h))
+
+    def grad_tensor(self):
+        """The flat device gradient buffer as a torch tensor ALIAS (no copy), for torch.distributed
+        all-reduce over RCCL.  torch is plumbing here: it only wraps the pointer."""
+        import torch
+        ptr, n = self.grad_device_ptr()
+
+        class _Ext:
+            __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (ptr, False), 'version': 3,
+                                        'strides': None}
+        return torch.as_tensor(_Ext(), device='cuda')
+
+    # ------------------------------------------------------------------ measurement
+    def set_profiling(self, on):
+        self._ck(self.lib.nasr_set_profiling(self.h, int(bool(on))))
+
+    def set_graph_mode(self, on):
+        self._ck(self.lib.nasr_set_graph_mode(self.h, int(bool(on))))
+
+    def phase_times(self):
+        pt = _lib.PhaseTimes()
+        self._ck(self.lib.nasr_get_phase_times(self.h, byref(pt)))
+        return pt.as_dict()
