@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — audio-frames/sec of the CTC training step (forward + CTC + backward + gradient
+all-reduce + Adam) on N MI355X, one process per GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): bilstm_ctc_net 3x500 bidirectional (concat merge),
+16 kHz / 26 MFCC / numcontext 10 => F = 546, C = 29, batch 16 per GPU, T = 500 frames, synthetic features
+resident in HBM, random-init weights.  `--workload literal` runs the reference's literal 1x500 BiLstmCTCNet
+(stack-reshape merge) instead; both are reported in DESIGN.md.  A "step" is one pass of the hot path over one
+resident batch; decode/LER are not on the timed path.  Weak scaling: every rank owns its own
+shard of 16 utterances; the only exchange is one RCCL all-reduce (sum) of the flat fp32 gradient buffer."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def workload_spec(name):
+    from oracle.nasr_oracle import ModelSpec      # shape bookkeeping + synthetic batch only
+    if name == 'literal':
+        return ModelSpec(546, 500, 1, True, 'stack_reshape', 29), 'bilstm_ctc_net literal 1x500 bi stack_reshape'
+    if name == 'lstm3':
+        return ModelSpec(546, 500, 3, False, 'none', 29), 'lstm_ctc_net 3x500 uni'
+    return ModelSpec(546, 500, 3, True, 'concat', 29), 'bilstm_ctc_net 3x500 bi concat'
+
+
+def algorithmic_bytes(spec, B, T):
+    """A (activations) + W (params + Adam) + R (recurrent weights re-streamed every
+    timestep, forward U and backward U^T).  Returns (A, W, R) in bytes per training step."""
+    N = B * T
+    D, H, C = spec.dirs, spec.hidden, spec.num_classes
+    A = 0
+    for l in range(spec.num_layers):
+        I = spec.layer_input(l)
+        A += 4 * N * (I + 6 * D * H + 15 * D * H + I + (I if l > 0 else 0))
+    rows = 2 if (spec.bidirectional and spec.merge == 'stack_reshape') else 1
+    A += 16 * N * C * rows
+    W = 40 * spec.param_count()
+    R = 2 * T * sum(D * 4 * H * H * 4 for _ in range(spec.num_layers))
+    return A, W, R
+
+
+def step_kernel_bytes(spec, B):
+    """Algorithmic bytes of ONE launch of the per-timestep recurrence kernel (one timestep, both
+    directions): the recurrent matrix U (or U^T) once + the per-frame activations it touches
+    (forward: 4 gate pre-activations in, 4 activations out, c, c_prev, h out, h state in/out;
+    BPTT: dG state in/out, 4 activations in, 4 dG out, c, c_prev, dOut, dc in/out)."""
+    D, H = spec.dirs, spec.hidden
+    u = D * 4 * H * H * 4
+    fwd = u + B * D * H * 4 * (4 + 4 + 1 + 1 + 1 + 2)
+    bwd = u + B * D * H * 4 * (8 + 4 + 4 + 1 + 1 + 1 + 2)
+    return fwd, bwd
+
+
+def cpu_baseline(spec, B, seed):
+    """The fp64 NumPy oracle (kind "port": our CPU restatement of the TF graph; TensorFlow itself is not
+    in this image — SURVEY.md D8) timed on a bounded sample of the same workload: same net, same batch
+    size, T cut so that one forward+backward takes ~10-30 s."""
+    from oracle import nasr_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    Tc = 24 if spec.num_layers > 1 else 60
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, Tc, seed=seed)
+    params = O.init_params(spec, seed=1)
+    t0 = time.time()
+    O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+    dt = time.time() - t0
+    return {'value': float(seq_len.sum() / dt), 'unit': 'frames/s', 'cores': int(thr), 'kind': 'port',
+            'sample': f'fp64 NumPy oracle, 1 fwd+bwd step of the same net at B={B}, T={Tc} ({int(seq_len.sum())} frames, '
+                      f'{dt:.1f} s); Adam excluded'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='bilstm3x500', choices=['bilstm3x500', 'literal', 'lstm3'])
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--frames', type=int, default=500)
+    ap.add_argument('--var-len', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from neuralasr_amd.engine import Engine
+    from oracle import nasr_oracle as O
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    spec, wname = workload_spec(args.workload)
+    B, T = args.batch, args.frames
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
+                 learning_rate=1e-4, device_id=local, stream=stream)
+    eng.set_graph_mode(not args.no_graph)
+    eng.set_params(O.flatten(O.init_params(spec, seed=1)).astype(np.float32))   # same weights on every rank
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1234 + rank, var_len=args.var_len)
+    eng.upload_batch(feats, seq_len, labels, label_len)
+    frames = eng.resident_frames()
+    gt = eng.grad_tensor() if world > 1 else None
+
+    def step():
+        eng.compute_grads()
+        if world > 1:
+            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+        eng.apply_adam(1.0 / world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ft = torch.tensor([frames], device='cuda', dtype=torch.float64)
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        total_frames = float(ft.item())
+    else:
+        total_frames = float(frames)
+    loss = eng.get_loss()
+
+    # ---- per-phase / per-launch timing with HIP events on the engine's stream (a few extra steps)
+    eng.set_profiling(True)
+    acc = None
+    NP = 3
+    for _ in range(NP):
+        step()
+        pt = eng.phase_times()
+        acc = pt if acc is None else {k: (acc[k] + v if k.endswith('_ms') else v) for k, v in pt.items()}
+    eng.set_profiling(False)
+    phases = {k: (v / NP if k.endswith('_ms') else v) for k, v in acc.items()}
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        A, W, R = algorithmic_bytes(spec, B, T)
+        fb, bb = step_kernel_bytes(spec, B)
+        fwd_us = phases['rec_fwd_ms'] * 1e3 / max(phases['rec_fwd_launches'], 1)
+        bwd_us = phases['rec_bwd_ms'] * 1e3 / max(phases['rec_bwd_launches'], 1)
+        dom_bwd = phases['rec_bwd_ms'] >= phases['rec_fwd_ms']
+        k_bytes, k_us = (bb, bwd_us) if dom_bwd else (fb, fwd_us)
+        achieved = k_bytes / (k_us * 1e-6) / 1e9
+        pmc = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc_path):
+            try:
+                pj = json.load(open(pmc_path))
+                pmc = pj.get(args.workload, {}).get('lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel')
+            except Exception:
+                pmc = None
+        out = {
+            'metric': 'audio-frames/sec (fwd+bwd+CTC+Adam) at batch 16 per GPU',
+            'value': total_frames * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': wname, 'batch_per_gpu': B, 'frames': T, 'feature_size': spec.feature_size,
+                       'hidden': spec.hidden, 'layers': spec.num_layers, 'classes': spec.num_classes,
+                       'var_len': bool(args.var_len), 'parallelism': f'dp{world}', 'hipgraph': not args.no_graph},
+            'loss': loss,
+            'roofline': {'bound': 'hbm', 'kernel': 'lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': pmc, 'bytes_per_launch': k_bytes, 'us_per_launch': k_us,
+                         'fwd_step_us': fwd_us, 'bwd_step_us': bwd_us},
+            'roofline_step': {'bound': 'hbm', 'bytes_alg': A + W + R, 'bytes_compulsory': A + W,
+                              'achieved': (A + W + R) / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': (A + W + R) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            'phases_ms': {k: round(v, 4) for k, v in phases.items() if k.endswith('_ms')},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(spec, B, 1234)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

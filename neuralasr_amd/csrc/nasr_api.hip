@@ -107,6 +107,7 @@ struct nasr_ctx {
   struct Span { int ph; hipEvent_t a, b; };
   std::vector<Span> spans;
   hipEvent_t ev_total_a = nullptr, ev_total_b = nullptr;
+  bool window_open = false, total_valid = false;   // timing window [upload|compute_grads .. apply_adam]
   int n_fwd_launch = 0, n_bwd_launch = 0;
   nasr_phase_times last_times;
 
@@ -364,7 +365,11 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
   const int Bp = h->Bp;
   h->ev_used = 0;
   h->spans.clear();
-  if (h->profiling) (void)hipEventRecord(h->ev_total_a, h->st);
+  if (h->profiling) {
+    (void)hipEventRecord(h->ev_total_a, h->st);
+    h->window_open = true;
+    h->total_valid = false;
+  }
   h->h_seq.assign((size_t)Bp, 0);
   h->frames = 0;
   for (int b = 0; b < B; ++b) {
@@ -817,10 +822,12 @@ int nasr_compute_grads(nasr_handle h) {
   if (!h) return NASR_ERR_ARG;
   if (!h->resident) return h->fail(NASR_ERR_STATE, "no resident batch");
   HIPCHK(h, hipSetDevice(h->device));
-  if (h->profiling && h->spans.size() > 1) {  // a fresh timing window per step when the batch stays resident
+  if (h->profiling && !h->window_open) {  // a fresh timing window per step when the batch stays resident
     h->ev_used = 0;
     h->spans.clear();
     (void)hipEventRecord(h->ev_total_a, h->st);
+    h->window_open = true;
+    h->total_valid = false;
   }
   int rc = forward(h);
   if (rc) return rc;
@@ -847,7 +854,11 @@ int nasr_apply_adam(nasr_handle h, float grad_scale) {
     int rc = repack(h);
     if (rc) return rc;
   }
-  if (h->profiling) (void)hipEventRecord(h->ev_total_b, h->st);
+  if (h->profiling && h->window_open) {
+    (void)hipEventRecord(h->ev_total_b, h->st);
+    h->window_open = false;
+    h->total_valid = true;
+  }
   h->have_grads = false;
   return NASR_OK;
 }
@@ -944,6 +955,8 @@ int nasr_set_profiling(nasr_handle h, int enabled) {
   h->profiling = enabled != 0;
   h->ev_used = 0;
   h->spans.clear();
+  h->window_open = false;
+  h->total_valid = false;
   return NASR_OK;
 }
 
@@ -960,7 +973,8 @@ int nasr_get_phase_times(nasr_handle h, nasr_phase_times* out) {
   t.pack_ms = acc[PH_PACK]; t.xproj_ms = acc[PH_XPROJ]; t.rec_fwd_ms = acc[PH_RECF]; t.proj_ctc_ms = acc[PH_PROJCTC];
   t.proj_bwd_ms = acc[PH_PROJB]; t.rec_bwd_ms = acc[PH_RECB]; t.wgrad_ms = acc[PH_WGRAD]; t.adam_ms = acc[PH_ADAM];
   float tot = 0.f;
-  if (h->profiling && hipEventElapsedTime(&tot, h->ev_total_a, h->ev_total_b) == hipSuccess) t.total_ms = tot;
+  if (h->total_valid && hipEventElapsedTime(&tot, h->ev_total_a, h->ev_total_b) == hipSuccess) t.total_ms = tot;
+  (void)hipGetLastError();
   t.rec_fwd_launches = h->n_fwd_launch;
   t.rec_bwd_launches = h->n_bwd_launch;
   *out = t;
