@@ -7,27 +7,40 @@
 // hoisted out of the loop into one MFMA GEMM (gemm.hip); what remains per step is the
 // [Bp,Hp]x[Hp,4Hp] recurrent product fused with the cell update.
 //
-// One launch = one timestep of BOTH directions (blockIdx.y).  A block owns 4 hidden units x 4 gates
-// = one 16-column MFMA tile of the gate-interleaved recurrent matrix, so Hp/4 * D blocks (256 for
-// 2x512) fill the chip; its 4 waves split K = Hp and reduce through LDS.  Operands are stored in HBM
-// in MFMA-fragment order ("swizzled"): lane l of k-step ks reads element 64*ks + l, four k-steps per
-// 16-byte load, so every wave load is one contiguous 1 KiB.  The recurrent weights (32 KB per block)
-// are re-read every step from the XCD's L2 (block -> XCD mapping is fixed across launches).
+// One launch = one timestep of BOTH directions (blockIdx.y).  Measured on MI355X (tools/stepbench.hip):
+// a dependent launch costs 1.55 us whatever its shape, and a CU pulls ~70 GB/s from its XCD's L2, so a
+// step is priced by BYTES PER CU, not by chip bandwidth.  Both kernels are therefore cut so that every
+// CU streams ~32 KB of recurrent weights (the matrices stay L2-resident across launches: block -> XCD
+// mapping is fixed) plus the smallest possible share of the step's state:
+//   forward : block = 4 hidden units x 4 gates (one 16-column MFMA tile), Hp/4 * D blocks (256 for
+//             2x512), its 4 waves split K = Hp and reduce through LDS; state = h (32 KB).
+//   backward: block = (64-unit output tile, 32-unit K slice); it rebuilds its slice of dG from the
+//             previous launch's partial sums, multiplies by its 32 KB tile of U^T and hands 16 x 64
+//             partial sums to the next launch (split-K across launches: deterministic, no atomics).
+// Operands are stored in HBM in MFMA-fragment order ("swizzled"), four k-steps per 16-byte load, so
+// every wave load is one contiguous 1 KiB.
 //
 // MFMA 16x16x4 f32 fragment maps: A[row = l&15][k = l>>4], B[k = l>>4][col = l&15],
 // C/D col = l&15, row = 4*(l>>4) + reg.
 #include "kernels.h"
 
+#ifndef NASR_ABL
+#define NASR_ABL 0   // tools/stepbench.hip ablation mask: 1 no U loads, 2 no h loads, 4 no MFMA, 8 no cell I/O
+#endif
+
 namespace nasr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
-// element (b16, k) of M-tile mt inside a swizzled A-operand image with contraction length Kd
+// Element (row b16, unit k) of M-tile mt inside the swizzled h-state image (contraction length Kd).
+// Lane l of 16-byte group q holds, in component i, the value the MFMA k-step 4q+i wants from lane l:
+// unit k = 16q + 4*(l>>4) + i, row l&15.  The 4 units x 16 rows one block produces are therefore one
+// contiguous 256-byte run (coalesced state write).
 __device__ __forceinline__ int sw_index(int Kd, int mt, int b16, int k) {
-  return ((((mt * (Kd >> 4) + (k >> 4)) * 64) + (k & 3) * 16 + b16) << 2) + ((k >> 2) & 3);
+  return ((((mt * (Kd >> 4) + (k >> 4)) * 64) + ((k >> 2) & 3) * 16 + b16) << 2) + (k & 3);
 }
 
 // ------------------------------------------------------------------ feature transpose + pad
@@ -51,24 +64,31 @@ void launch_pack_feats(const float* feats_bm, float* X0, int B, int Bp, int T, i
 
 // ------------------------------------------------------------------ recurrent weight repack
 // U [Hp][N4] (row k = h unit, col n = 4*j+g) ->
-//   Uf [N4/16 tiles][Hp/16][64][4] : Uf[tile][q][l][i] = U[16q+4i+(l>>4)][16*tile+(l&15)]   (fwd B operand)
-//   Ub [Hp/16 tiles][N4/16][64][4] : Ub[jt][q][l][i]   = U[16*jt+(l&15)][16q+4i+(l>>4)]     (bwd B operand = U^T)
+//   Uf [N4/16 tiles][Hp/16][64][4] : Uf[tile][q][l][i] = U[16q + 4*(l>>4) + i][16*tile + (l&15)]
+//        forward B operand; k-step 4q+i contracts units {16q + 4*sub + i}, matching sw_index().
+//   Ub [Hp/64 jt][Hp/32 ks][4 w][4 nt][2 q2][64][4] :
+//        Ub[..][l][i] = U[64jt + 16nt + (l&15)][4*(32ks + 4*(4q2+i) + (l>>4)) + w]
+//        backward B operand (= U^T): block (jt,ks), wave w = gate w, k-step 4q2+i contracts the
+//        slice-local units {4*(4q2+i) + sub}.
 __global__ __launch_bounds__(256) void repack_u_kernel(const float* __restrict__ U, float* __restrict__ Uf,
                                                        float* __restrict__ Ub, int Hp) {
   const int N4 = 4 * Hp;
   const int64_t total = (int64_t)Hp * N4;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = e & 3, l = (e >> 2) & 63;
     {  // forward image
-      const int i = e & 3, l = (e >> 2) & 63;
       const int64_t tq = e >> 8;
       const int q = (int)(tq % (Hp >> 4)), tile = (int)(tq / (Hp >> 4));
-      Uf[e] = U[(size_t)(16 * q + 4 * i + (l >> 4)) * N4 + 16 * tile + (l & 15)];
+      Uf[e] = U[(size_t)(16 * q + 4 * (l >> 4) + i) * N4 + 16 * tile + (l & 15)];
     }
     {  // backward image
-      const int i = e & 3, l = (e >> 2) & 63;
-      const int64_t tq = e >> 8;
-      const int q = (int)(tq % (N4 >> 4)), jt = (int)(tq / (N4 >> 4));
-      Ub[e] = U[(size_t)(16 * jt + (l & 15)) * N4 + 16 * q + 4 * i + (l >> 4)];
+      int64_t x = e >> 8;
+      const int q2 = (int)(x & 1); x >>= 1;
+      const int nt = (int)(x & 3); x >>= 2;
+      const int w = (int)(x & 3); x >>= 2;
+      const int ks = (int)(x % (Hp >> 5)), jt = (int)(x / (Hp >> 5));
+      const int ju = 4 * (4 * q2 + i) + (l >> 4);
+      Ub[e] = U[(size_t)(64 * jt + 16 * nt + (l & 15)) * N4 + 4 * (32 * ks + ju) + w];
     }
   }
 }
@@ -87,6 +107,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
   __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.x, d = blockIdx.y;
+  if ((NASR_ABL & 64) && s != 123456) return;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
   const int nq = Hp >> 6;          // float4 groups per wave (K quarter)
   const int q0 = w * nq;
@@ -103,17 +124,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
   float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
   float cprev = 0.f;
   if (cell) {
-    len = seq_len[b];
+    len = (NASR_ABL & 16) ? T : seq_len[b];
     valid = s < len;
     if (valid) {
       const int tb = d ? (len - 1 - s) : s;
       r = tb * Bp + b;
-      xg = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);
-      if (s > 0) cprev = cbuf[(size_t)(d ? r + Bp : r - Bp) * DH + d * Hp + j];
+      if (!(NASR_ABL & 8)) {
+        xg = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);
+        if (s > 0) cprev = cbuf[(size_t)(d ? r + Bp : r - Bp) * DH + d * Hp + j];
+      }
     }
   }
 
-  // ---- recurrent product: acc[mt] (16 x 16) over this wave's K quarter
+  // ---- recurrent product: acc[mt] (16 x 16) over this wave's K quarter.  Loads are issued in
+  // consumption order (h, U, h, U, ...) so the MFMA chain starts when the first pair lands.
   const float4* ub = reinterpret_cast<const float4*>(Uf) + ((size_t)(d * (Hp >> 2) + tile) * (Hp >> 4) + q0) * 64 + lane;
   const float4* ha = reinterpret_cast<const float4*>(hin) + ((size_t)d * MT * (Hp >> 4) + q0) * 64 + lane;
   f32x4 acc[MT][2];
@@ -126,18 +150,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
     float4 bu[8];
     float4 av[MT][8];
 #pragma unroll
-    for (int x = 0; x < 8; ++x)
-      if (qc + x < nq) bu[x] = ub[(size_t)(qc + x) * 64];
+    for (int x = 0; x < 8; ++x) {
+      if (qc + x < nq) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int x = 0; x < 8; ++x)
-        if (qc + x < nq) av[m][x] = ha[((size_t)m * (Hp >> 4) + qc + x) * 64];
+        for (int m = 0; m < MT; ++m)
+          av[m][x] = (NASR_ABL & 2) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ha[((size_t)m * (Hp >> 4) + qc + x) * 64];
+        bu[x] = (NASR_ABL & 1) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ub[(size_t)(qc + x) * 64];
+      }
+    }
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
       if (qc + x < nq) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+          if (NASR_ABL & 4) {
+            acc[m][0][0] += av[m][x].x * bu[x].x + av[m][x].y * bu[x].y + av[m][x].z * bu[x].z + av[m][x].w * bu[x].w;
+            continue;
+          }
           acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].x, bu[x].x, acc[m][0], 0, 0, 0);
           acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].y, bu[x].y, acc[m][1], 0, 0, 0);
           acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].z, bu[x].z, acc[m][0], 0, 0, 0);
@@ -168,10 +197,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
       const float so = sigmoidf_(xg.w + g[3]);
       const float c = cprev * sf + si * tj;
       const float h = tanhf_(c) * so;
-      *reinterpret_cast<float4*>(gates + (size_t)r * DN + d * N4 + 4 * j) = make_float4(si, tj, sf, so);
-      cbuf[(size_t)r * DH + d * Hp + j] = c;
-      out[(size_t)r * DH + d * Hp + j] = h;
-      *hdst = h;
+      if (!(NASR_ABL & 8)) {
+        *reinterpret_cast<float4*>(gates + (size_t)r * DN + d * N4 + 4 * j) = make_float4(si, tj, sf, so);
+        cbuf[(size_t)r * DH + d * Hp + j] = c;
+        out[(size_t)r * DH + d * Hp + j] = h;
+      }
+      if (!(NASR_ABL & 32) || h == 123.456f) *hdst = h;
     } else {
       // frame s of row b is past seq_len for both directions: zero output (A.2); state is dead
       if (s < T) out[((size_t)s * Bp + b) * DH + d * Hp + j] = 0.f;
@@ -197,108 +228,131 @@ void launch_lstm_fwd_step(const LstmDims& dm, int s, const float* Uf, const floa
 }
 
 // ------------------------------------------------------------------ BPTT step
-// Block = 16 hidden units of one direction.  Phase 1: dh_rec[b][j] = sum_n dG_{next}[b][n] U[j][n]
-// (K = N4 split over the 4 waves).  Phase 2 (thread = (b, j)): add the gradient from above,
-// gate derivatives from the saved activations, write dG for this frame in place over the
-// activations (frame-indexed, consumed by the weight-gradient GEMMs) and in swizzled A-operand
-// order for the next step.  Masked frames get dG = 0 so the GEMMs need no mask.
+// grid.x = (Hp/64 output tiles jt) x (Hp/32 K slices ks), blockIdx.x = jt*KSPLIT + ks so the blocks that
+// rebuild the same dG slice share an XCD (ids equal mod 8).  Per block and step:
+//   P: for its 32 units x Bp rows: dh = sum_k partial_in[k] + dOut (gradient from above), gate
+//      derivatives from the saved activations -> dG slice [Bp x 128] into LDS (k order g*32+ju);
+//      the jt == 0 block also stores dG frame-indexed (for the weight-gradient GEMMs) and dc.
+//   G: partial_out[ks][b][64jt..] = dG_slice x U^T tile on v_mfma_f32_16x16x4 (wave w = gate w),
+//      4-wave LDS reduction, plain stores.  The next launch sums the KSPLIT partials in fixed order.
+// Masked frames get dG = 0 so the GEMMs need no mask.
 template <int MT>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
-    const float* __restrict__ Ub,    // [D][Hp/16][N4/16][64][4]
-    const float* __restrict__ dgin,  // [D][MT][N4/16][64][4]
-    float* __restrict__ dgout, float* __restrict__ gates, const float* __restrict__ cbuf,
-    const float* __restrict__ dout, float* __restrict__ dcstate, const int* __restrict__ seq_len, int s, int T,
-    int Bp, int Hp, int D) {
-  __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
+    const float* __restrict__ Ub,     // [D][Hp/64][Hp/32][4][4][2][64][4]
+    const float* __restrict__ pin,    // [D][KSPLIT][Bp][Hp] partial sums of dh_rec from the previous launch
+    float* __restrict__ pout,
+    const float* __restrict__ gates,  // [R][D*N4] activations si,tj,sf,so
+    float* __restrict__ dgbuf,        // [R][D*N4] dG, frame indexed
+    const float* __restrict__ cbuf, const float* __restrict__ dout, const float* __restrict__ dcin,
+    float* __restrict__ dcout, const int* __restrict__ seq_len, int s, int T, int Bp, int Hp, int D) {
+  __shared__ __attribute__((aligned(16))) float As[MT][128][17];
+  __shared__ __attribute__((aligned(16))) float red[4][MT][4][64][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int jt = blockIdx.x, d = blockIdx.y;
+  const int KSPLIT = Hp >> 5;
+  const int jt = blockIdx.x / KSPLIT, ks = blockIdx.x % KSPLIT, d = blockIdx.y;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
-  const int nq = N4 >> 6;
-  const int q0 = w * nq;
 
-  const float4* ub = reinterpret_cast<const float4*>(Ub) + ((size_t)(d * (Hp >> 4) + jt) * (N4 >> 4) + q0) * 64 + lane;
-  const float4* ga = reinterpret_cast<const float4*>(dgin) + ((size_t)d * MT * (N4 >> 4) + q0) * 64 + lane;
-  f32x4 acc[MT][2];
+  // ---- this wave's 8 B-operand fragments (32 KB per block), in flight during the P stage
+  const float4* ub = reinterpret_cast<const float4*>(Ub) +
+                     ((((size_t)(d * (Hp >> 6) + jt) * KSPLIT + ks) * 4 + w) * 8) * 64 + lane;
+  float4 bu[4][2];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) bu[nt][q2] = ub[(size_t)(nt * 2 + q2) * 64];
+
+  // ---- P stage
+  const float* pbase = pin + (size_t)d * KSPLIT * Bp * Hp;
+#pragma unroll
+  for (int ci = 0; ci < 2 * MT; ++ci) {
+    const int c = tid + 256 * ci;
+    const int ju = c & 31, b = c >> 5;
+    const int mt = b >> 4, b16 = b & 15;
+    const int j = 32 * ks + ju;
+    const int len = seq_len[b];
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dcn = 0.f;
+    if (s < len) {
+      const int tb = d ? (len - 1 - s) : s;
+      const int r = tb * Bp + b;
+      const float4 a = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);  // si,tj,sf,so
+      const float cc = cbuf[(size_t)r * DH + d * Hp + j];
+      const float cp = s > 0 ? cbuf[(size_t)(d ? r + Bp : r - Bp) * DH + d * Hp + j] : 0.f;
+      float dh = dout[(size_t)r * DH + d * Hp + j];
+      const float dci = dcin[((size_t)d * Bp + b) * Hp + j];
+      const float* pp = pbase + (size_t)b * Hp + j;
+#pragma unroll 8
+      for (int k = 0; k < KSPLIT; ++k) dh += pp[(size_t)k * Bp * Hp];
+      const float tc = tanhf_(cc);
+      const float dct = dci + dh * a.w * (1.f - tc * tc);
+      dg.x = dct * a.y * a.x * (1.f - a.x);
+      dg.y = dct * a.x * (1.f - a.y * a.y);
+      dg.z = dct * cp * a.z * (1.f - a.z);
+      dg.w = dh * tc * a.w * (1.f - a.w);
+      dcn = dct * a.z;
+      if (jt == 0) *reinterpret_cast<float4*>(dgbuf + (size_t)r * DN + d * N4 + 4 * j) = dg;
+    } else if (jt == 0 && s < T) {
+      *reinterpret_cast<float4*>(dgbuf + ((size_t)s * Bp + b) * DN + d * N4 + 4 * j) = dg;
+    }
+    if (jt == 0) dcout[((size_t)d * Bp + b) * Hp + j] = dcn;
+    As[mt][0 * 32 + ju][b16] = dg.x;
+    As[mt][1 * 32 + ju][b16] = dg.y;
+    As[mt][2 * 32 + ju][b16] = dg.z;
+    As[mt][3 * 32 + ju][b16] = dg.w;
   }
-  for (int qc = 0; qc < nq; qc += 8) {
-    float4 bu[8];
-    float4 av[MT][8];
+  __syncthreads();
+
+  // ---- G stage: wave w contracts k_local in [32w, 32w+32) (gate w) for the 4 N-tiles
+  f32x4 acc[MT][4];
 #pragma unroll
-    for (int x = 0; x < 8; ++x)
-      if (qc + x < nq) bu[x] = ub[(size_t)(qc + x) * 64];
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int nt = 0; nt < 4; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int x = 0; x < 8; ++x)
-        if (qc + x < nq) av[m][x] = ga[((size_t)m * (N4 >> 4) + qc + x) * 64];
+  for (int q2 = 0; q2 < 2; ++q2) {
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      if (qc + x < nq) {
+    for (int i = 0; i < 4; ++i) {
+      const int kl = 32 * w + 4 * (4 * q2 + i) + (lane >> 4);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].x, bu[x].x, acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].y, bu[x].y, acc[m][1], 0, 0, 0);
-          acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].z, bu[x].z, acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].w, bu[x].w, acc[m][1], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) {
+        const float a = As[m][kl][lane & 15];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float bv = i == 0 ? bu[nt][q2].x : i == 1 ? bu[nt][q2].y : i == 2 ? bu[nt][q2].z : bu[nt][q2].w;
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[m][nt], 0, 0, 0);
         }
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    f32x4 sacc = acc[m][0] + acc[m][1];
-    *reinterpret_cast<f32x4*>(&red[w][m][lane][0]) = sacc;
-  }
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(&red[w][m][nt][lane][0]) = acc[m][nt];
   __syncthreads();
 
-  const int b16 = tid & 15, ju = tid >> 4;
-  const int j = jt * 16 + ju;
+  // ---- wave w finalises N-tile w: C/D map col = lane&15 (unit), row = 4*(lane>>4)+reg (batch row)
+  float* po = pout + ((size_t)d * KSPLIT + ks) * Bp * Hp;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int b = m * 16 + b16;
-    const int len = seq_len[b];
-    float* dgs = dgout + (size_t)d * MT * N4 * 16;
-    float* dcs = dcstate + ((size_t)d * Bp + b) * Hp + j;
-    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s < len) {
-      const int tb = d ? (len - 1 - s) : s;
-      const int r = tb * Bp + b;
-      const int ls = 16 * (b16 >> 2) + ju, rg = b16 & 3;
-      const float dh = red[0][m][ls][rg] + red[1][m][ls][rg] + red[2][m][ls][rg] + red[3][m][ls][rg] +
-                       dout[(size_t)r * DH + d * Hp + j];
-      const float4 a = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);  // si,tj,sf,so
-      const float c = cbuf[(size_t)r * DH + d * Hp + j];
-      const float cp = s > 0 ? cbuf[(size_t)(d ? r + Bp : r - Bp) * DH + d * Hp + j] : 0.f;
-      const float tc = tanhf_(c);
-      const float dct = *dcs + dh * a.w * (1.f - tc * tc);
-      dg.x = dct * a.y * a.x * (1.f - a.x);
-      dg.y = dct * a.x * (1.f - a.y * a.y);
-      dg.z = dct * cp * a.z * (1.f - a.z);
-      dg.w = dh * tc * a.w * (1.f - a.w);
-      *dcs = dct * a.z;
-      *reinterpret_cast<float4*>(gates + (size_t)r * DN + d * N4 + 4 * j) = dg;
-    } else {
-      *dcs = 0.f;
-      if (s < T) *reinterpret_cast<float4*>(gates + ((size_t)s * Bp + b) * DN + d * N4 + 4 * j) = dg;
-    }
-    dgs[sw_index(N4, m, b16, 4 * j + 0)] = dg.x;
-    dgs[sw_index(N4, m, b16, 4 * j + 1)] = dg.y;
-    dgs[sw_index(N4, m, b16, 4 * j + 2)] = dg.z;
-    dgs[sw_index(N4, m, b16, 4 * j + 3)] = dg.w;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][m][w][lane][0]) +
+                    *reinterpret_cast<const f32x4*>(&red[1][m][w][lane][0]) +
+                    *reinterpret_cast<const f32x4*>(&red[2][m][w][lane][0]) +
+                    *reinterpret_cast<const f32x4*>(&red[3][m][w][lane][0]);
+    const int jo = 64 * jt + 16 * w + (lane & 15);
+    const int b0 = 16 * m + 4 * (lane >> 4);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) po[(size_t)(b0 + rg) * Hp + jo] = v[rg];
   }
 }
 
-void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const float* dgin, float* dgout, float* gates,
-                          const float* cbuf, const float* dout, float* dcstate, const int* seq_len, hipStream_t st) {
-  dim3 grid(dm.Hp / 16, dm.D), block(256);
+void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const float* pin, float* pout,
+                          const float* gates, float* dgbuf, const float* cbuf, const float* dout, const float* dcin,
+                          float* dcout, const int* seq_len, hipStream_t st) {
+  dim3 grid((dm.Hp / 64) * (dm.Hp / 32), dm.D), block(256);
   const int MT = dm.Bp / 16;
-#define NASR_BWD(MTV)                                                                                         \
-  hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV>), grid, block, 0, st, Ub, dgin, dgout, gates, cbuf, dout, \
-                     dcstate, seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D)
+#define NASR_BWD(MTV)                                                                                          \
+  hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV>), grid, block, 0, st, Ub, pin, pout, gates, dgbuf, cbuf, dout, \
+                     dcin, dcout, seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D)
   switch (MT) {
     case 1: NASR_BWD(1); break;
     case 2: NASR_BWD(2); break;

@@ -92,7 +92,7 @@ struct nasr_ctx {
   int64_t frames = 0;
   std::vector<int32_t> h_seq;
 
-  DevBuf feats_bm, X0, dout, hstate, dgstate, dcstate, logits, logz, alpha, beta, nll, loss, seq, labels, lablen,
+  DevBuf feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, logits, logz, alpha, beta, nll, loss, seq, labels, lablen,
       rowmap, slabs, csws, amax, ids, lens, stage;
   std::vector<DevBuf> gates, outb, cbuf;
 
@@ -300,8 +300,9 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->X0.ensure(R * h->Fp * 4, &grew);
   ok &= h->dout.ensure(R * D * Hp * 4, &grew);
   ok &= h->hstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
-  ok &= h->dgstate.ensure((size_t)2 * D * Bp * N4 * 4, &grew);
-  ok &= h->dcstate.ensure((size_t)D * Bp * Hp * 4, &grew);
+  ok &= h->partial.ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
+  ok &= h->dcstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
+  ok &= h->dgbuf.ensure(R * D * N4 * 4, &grew);
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
   const int KSa = KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations
@@ -417,7 +418,7 @@ int run_steps(nasr_ctx* h, int l, bool bwd) {
   const LstmDims dm{h->T, h->B, h->Bp, h->H, h->Hp, h->D};
   const size_t sU = (size_t)l * h->D * h->Hp * h->N4;
   const size_t hs = (size_t)h->D * h->Bp * h->Hp;   // one h-state image
-  const size_t gs = (size_t)h->D * h->Bp * h->N4;   // one dG-state image
+  const size_t ps = (size_t)h->D * (h->Hp / 32) * h->Bp * h->Hp;   // one partial-sum image
   auto body = [&]() {
     if (!bwd) {
       (void)hipMemsetAsync(h->hstate.p, 0, hs * 4, h->st);
@@ -427,14 +428,15 @@ int run_steps(nasr_ctx* h, int l, bool bwd) {
                              h->cbuf[l].as<float>(), h->outb[l].as<float>(), h->seq.as<int>(), h->cfg.forget_bias,
                              h->st);
     } else {
-      (void)hipMemsetAsync(h->dgstate.p, 0, gs * 4, h->st);
+      (void)hipMemsetAsync(h->partial.p, 0, ps * 4, h->st);
       (void)hipMemsetAsync(h->dcstate.p, 0, hs * 4, h->st);
       int k = 0;
       for (int s = h->T - 1; s >= 0; --s, ++k)
-        launch_lstm_bwd_step(dm, s, h->Ub + sU, h->dgstate.as<float>() + (k & 1) * gs,
-                             h->dgstate.as<float>() + ((k + 1) & 1) * gs, h->gates[l].as<float>(),
-                             h->cbuf[l].as<float>(), h->dout.as<float>(), h->dcstate.as<float>(), h->seq.as<int>(),
-                             h->st);
+        launch_lstm_bwd_step(dm, s, h->Ub + sU, h->partial.as<float>() + (k & 1) * ps,
+                             h->partial.as<float>() + ((k + 1) & 1) * ps, h->gates[l].as<float>(),
+                             h->dgbuf.as<float>(), h->cbuf[l].as<float>(), h->dout.as<float>(),
+                             h->dcstate.as<float>() + (k & 1) * hs, h->dcstate.as<float>() + ((k + 1) & 1) * hs,
+                             h->seq.as<int>(), h->st);
     }
   };
   if (!h->graph_mode) {
@@ -576,7 +578,7 @@ int backward(nasr_ctx* h) {
     }
     PhaseScope ps(h, PH_WGRAD);
     const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
-    float* dG = h->gates[l].as<float>();
+    float* dG = h->dgbuf.as<float>();
     {  // dWx = X^T dG
       GemmDesc g{};
       g.A = Xl; g.B = dG; g.C = h->G + h->off_wx[l];
@@ -613,7 +615,6 @@ int backward(nasr_ctx* h) {
     HIPCHK(h, hipGetLastError());
   }
   h->have_grads = true;
-  h->have_fwd = false;  // activations were overwritten by dG
   return NASR_OK;
 }
 
@@ -718,7 +719,7 @@ int nasr_destroy(nasr_handle h) {
   drop_graphs(h);
   for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub})
     if (p) (void)hipFree(p);
-  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->dgstate, &h->dcstate, &h->logits, &h->logz,
+  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
     b->release();
