@@ -98,7 +98,10 @@ void launch_repack_u(const float* U, float* Uf, float* Ub, int Hp, hipStream_t s
 }
 
 // ------------------------------------------------------------------ forward step
-template <int MT>
+// NQ = Hp/64 (16-byte operand groups per wave) as a template constant keeps the load/MFMA stream
+// straight-line, so hipcc emits counted vmcnt waits and the MFMA chain starts when the first pair lands;
+// NQ = 0 is the generic (runtime) form.
+template <int MT, int NQ>
 __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
     const float* __restrict__ Uf,    // [D][Hp/4][Hp/16][64][4]
     const float* __restrict__ hin,   // [D][MT][Hp/16][64][4]
@@ -109,14 +112,32 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
   const int tile = blockIdx.x, d = blockIdx.y;
   if ((NASR_ABL & 64) && s != 123456) return;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
-  const int nq = Hp >> 6;          // float4 groups per wave (K quarter)
+  const int nq = NQ > 0 ? NQ : (Hp >> 6);   // float4 groups per wave (K quarter)
   const int q0 = w * nq;
+  constexpr int CH = NQ == 0 ? 1 : (NQ < 8 ? NQ : 8);
 
-  // ---- cell threads: issue the loads the cell update needs before the GEMM
-  const bool cell = tid < 64 * MT;
+  // seq_len first: vmcnt retires in order, so the wait on it must not sit behind the operand stream
   const int cmt = tid >> 6, cl = tid & 63;
   const int b16 = cl & 15, u = cl >> 4;
   const int b = cmt * 16 + b16;
+  const int len_ld = (NASR_ABL & 16) ? T : seq_len[b < Bp ? b : 0];
+
+  // ---- recurrent product: acc[mt] (16 x 16) over this wave's K quarter.  Loads are issued in
+  // consumption order (h, U, h, U, ...) ahead of everything else.
+  const float4* ub = reinterpret_cast<const float4*>(Uf) + ((size_t)(d * (Hp >> 2) + tile) * (Hp >> 4) + q0) * 64 + lane;
+  const float4* ha = reinterpret_cast<const float4*>(hin) + ((size_t)d * MT * (Hp >> 4) + q0) * 64 + lane;
+  float4 bu[CH];
+  float4 av[MT][CH];
+#pragma unroll
+  for (int x = 0; x < CH; ++x) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      av[m][x] = (NASR_ABL & 2) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ha[((size_t)m * (Hp >> 4) + x) * 64];
+    bu[x] = (NASR_ABL & 1) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ub[(size_t)x * 64];
+  }
+
+  // ---- cell threads: issue the loads the cell update needs
+  const bool cell = tid < 64 * MT;
   const int j = tile * 4 + u;
   int len = 0;
   bool valid = false;
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
   float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
   float cprev = 0.f;
   if (cell) {
-    len = (NASR_ABL & 16) ? T : seq_len[b];
+    len = len_ld;
     valid = s < len;
     if (valid) {
       const int tb = d ? (len - 1 - s) : s;
@@ -136,42 +157,33 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
     }
   }
 
-  // ---- recurrent product: acc[mt] (16 x 16) over this wave's K quarter.  Loads are issued in
-  // consumption order (h, U, h, U, ...) so the MFMA chain starts when the first pair lands.
-  const float4* ub = reinterpret_cast<const float4*>(Uf) + ((size_t)(d * (Hp >> 2) + tile) * (Hp >> 4) + q0) * 64 + lane;
-  const float4* ha = reinterpret_cast<const float4*>(hin) + ((size_t)d * MT * (Hp >> 4) + q0) * 64 + lane;
   f32x4 acc[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int qc = 0; qc < nq; qc += 8) {
-    float4 bu[8];
-    float4 av[MT][8];
+  for (int qc = 0; qc < nq; qc += CH) {
+    if (qc > 0) {
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      if (qc + x < nq) {
+      for (int x = 0; x < CH; ++x) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          av[m][x] = (NASR_ABL & 2) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ha[((size_t)m * (Hp >> 4) + qc + x) * 64];
-        bu[x] = (NASR_ABL & 1) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ub[(size_t)(qc + x) * 64];
+        for (int m = 0; m < MT; ++m) av[m][x] = ha[((size_t)m * (Hp >> 4) + qc + x) * 64];
+        bu[x] = ub[(size_t)(qc + x) * 64];
       }
     }
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      if (qc + x < nq) {
+    for (int x = 0; x < CH; ++x) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          if (NASR_ABL & 4) {
-            acc[m][0][0] += av[m][x].x * bu[x].x + av[m][x].y * bu[x].y + av[m][x].z * bu[x].z + av[m][x].w * bu[x].w;
-            continue;
-          }
-          acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].x, bu[x].x, acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].y, bu[x].y, acc[m][1], 0, 0, 0);
-          acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].z, bu[x].z, acc[m][0], 0, 0, 0);
-          acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].w, bu[x].w, acc[m][1], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) {
+        if (NASR_ABL & 4) {
+          acc[m][0][0] += av[m][x].x * bu[x].x + av[m][x].y * bu[x].y + av[m][x].z * bu[x].z + av[m][x].w * bu[x].w;
+          continue;
         }
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].x, bu[x].x, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].y, bu[x].y, acc[m][1], 0, 0, 0);
+        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].z, bu[x].z, acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][x].w, bu[x].w, acc[m][1], 0, 0, 0);
       }
     }
   }
@@ -214,16 +226,26 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
 void launch_lstm_fwd_step(const LstmDims& dm, int s, const float* Uf, const float* hin, float* hout, float* gates,
                           float* cbuf, float* out, const int* seq_len, float forget_bias, hipStream_t st) {
   dim3 grid(dm.Hp / 4, dm.D), block(256);
-  const int MT = dm.Bp / 16;
-#define NASR_FWD(MTV)                                                                                            \
-  hipLaunchKernelGGL((lstm_fwd_step_kernel<MTV>), grid, block, 0, st, Uf, hin, hout, gates, cbuf, out, seq_len, \
-                     s, dm.T, dm.Bp, dm.Hp, dm.D, forget_bias)
-  switch (MT) {
-    case 1: NASR_FWD(1); break;
-    case 2: NASR_FWD(2); break;
-    case 3: NASR_FWD(3); break;
-    default: NASR_FWD(4); break;
+  const int MT = dm.Bp / 16, nq = dm.Hp / 64;
+#define NASR_FWD(MTV, NQV)                                                                                     \
+  hipLaunchKernelGGL((lstm_fwd_step_kernel<MTV, NQV>), grid, block, 0, st, Uf, hin, hout, gates, cbuf, out, \
+                     seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D, forget_bias)
+#define NASR_FWD_NQ(MTV)                                  \
+  switch (nq) {                                           \
+    case 1: NASR_FWD(MTV, 1); break;                      \
+    case 2: NASR_FWD(MTV, 2); break;                      \
+    case 4: NASR_FWD(MTV, 4); break;                      \
+    case 8: NASR_FWD(MTV, 8); break;                      \
+    case 16: NASR_FWD(MTV, 16); break;                    \
+    default: NASR_FWD(MTV, 0); break;                     \
   }
+  switch (MT) {
+    case 1: NASR_FWD_NQ(1); break;
+    case 2: NASR_FWD_NQ(2); break;
+    case 3: NASR_FWD_NQ(3); break;
+    default: NASR_FWD_NQ(4); break;
+  }
+#undef NASR_FWD_NQ
 #undef NASR_FWD
 }
 
@@ -236,7 +258,7 @@ void launch_lstm_fwd_step(const LstmDims& dm, int s, const float* Uf, const floa
 //   G: partial_out[ks][b][64jt..] = dG_slice x U^T tile on v_mfma_f32_16x16x4 (wave w = gate w),
 //      4-wave LDS reduction, plain stores.  The next launch sums the KSPLIT partials in fixed order.
 // Masked frames get dG = 0 so the GEMMs need no mask.
-template <int MT>
+template <int MT, int KSP>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
     const float* __restrict__ Ub,     // [D][Hp/64][Hp/32][4][4][2][64][4]
     const float* __restrict__ pin,    // [D][KSPLIT][Bp][Hp] partial sums of dh_rec from the previous launch
@@ -248,7 +270,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
   __shared__ __attribute__((aligned(16))) float As[MT][128][17];
   __shared__ __attribute__((aligned(16))) float red[4][MT][4][64][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int KSPLIT = Hp >> 5;
+  const int KSPLIT = KSP > 0 ? KSP : (Hp >> 5);
   const int jt = blockIdx.x / KSPLIT, ks = blockIdx.x % KSPLIT, d = blockIdx.y;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
 
@@ -261,44 +283,76 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) bu[nt][q2] = ub[(size_t)(nt * 2 + q2) * 64];
 
-  // ---- P stage
+  // ---- P stage: 2*MT cells per thread, processed in pairs: every load of a pair is issued before any
+  // of its arithmetic so the two latency chains overlap.
   const float* pbase = pin + (size_t)d * KSPLIT * Bp * Hp;
+  constexpr int KV = KSP > 0 ? KSP : 1;
 #pragma unroll
-  for (int ci = 0; ci < 2 * MT; ++ci) {
-    const int c = tid + 256 * ci;
-    const int ju = c & 31, b = c >> 5;
-    const int mt = b >> 4, b16 = b & 15;
-    const int j = 32 * ks + ju;
-    const int len = seq_len[b];
-    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
-    float dcn = 0.f;
-    if (s < len) {
-      const int tb = d ? (len - 1 - s) : s;
+  for (int cp2 = 0; cp2 < MT; ++cp2) {
+    int lenv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) lenv[e] = seq_len[(tid + 256 * (2 * cp2 + e)) >> 5];
+    float4 a[2];
+    float cc[2], cpv[2], dh[2], dci[2], pv[2][KV];
+    int rr[2];
+    bool val[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + 256 * (2 * cp2 + e);
+      const int ju = c & 31, b = c >> 5;
+      const int j = 32 * ks + ju;
+      val[e] = s < lenv[e];
+      const int tb = val[e] ? (d ? (lenv[e] - 1 - s) : s) : 0;
       const int r = tb * Bp + b;
-      const float4 a = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);  // si,tj,sf,so
-      const float cc = cbuf[(size_t)r * DH + d * Hp + j];
-      const float cp = s > 0 ? cbuf[(size_t)(d ? r + Bp : r - Bp) * DH + d * Hp + j] : 0.f;
-      float dh = dout[(size_t)r * DH + d * Hp + j];
-      const float dci = dcin[((size_t)d * Bp + b) * Hp + j];
-      const float* pp = pbase + (size_t)b * Hp + j;
-#pragma unroll 8
-      for (int k = 0; k < KSPLIT; ++k) dh += pp[(size_t)k * Bp * Hp];
-      const float tc = tanhf_(cc);
-      const float dct = dci + dh * a.w * (1.f - tc * tc);
-      dg.x = dct * a.y * a.x * (1.f - a.x);
-      dg.y = dct * a.x * (1.f - a.y * a.y);
-      dg.z = dct * cp * a.z * (1.f - a.z);
-      dg.w = dh * tc * a.w * (1.f - a.w);
-      dcn = dct * a.z;
-      if (jt == 0) *reinterpret_cast<float4*>(dgbuf + (size_t)r * DN + d * N4 + 4 * j) = dg;
-    } else if (jt == 0 && s < T) {
-      *reinterpret_cast<float4*>(dgbuf + ((size_t)s * Bp + b) * DN + d * N4 + 4 * j) = dg;
+      rr[e] = r;
+      a[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      cc[e] = cpv[e] = dh[e] = dci[e] = 0.f;
+      if (val[e]) {
+        a[e] = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);  // si,tj,sf,so
+        cc[e] = cbuf[(size_t)r * DH + d * Hp + j];
+        if (s > 0) cpv[e] = cbuf[(size_t)(d ? r + Bp : r - Bp) * DH + d * Hp + j];
+        dh[e] = dout[(size_t)r * DH + d * Hp + j];
+        dci[e] = dcin[((size_t)d * Bp + b) * Hp + j];
+        const float* pp = pbase + (size_t)b * Hp + j;
+        if (KSP > 0) {
+#pragma unroll
+          for (int k = 0; k < KV; ++k) pv[e][k] = pp[(size_t)k * Bp * Hp];
+        } else {
+          float acc0 = 0.f;
+          for (int k = 0; k < KSPLIT; ++k) acc0 += pp[(size_t)k * Bp * Hp];
+          pv[e][0] = acc0;
+        }
+      }
     }
-    if (jt == 0) dcout[((size_t)d * Bp + b) * Hp + j] = dcn;
-    As[mt][0 * 32 + ju][b16] = dg.x;
-    As[mt][1 * 32 + ju][b16] = dg.y;
-    As[mt][2 * 32 + ju][b16] = dg.z;
-    As[mt][3 * 32 + ju][b16] = dg.w;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = tid + 256 * (2 * cp2 + e);
+      const int ju = c & 31, b = c >> 5;
+      const int mt = b >> 4, b16 = b & 15;
+      const int j = 32 * ks + ju;
+      float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+      float dcn = 0.f;
+      if (val[e]) {
+        float dhs = dh[e];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) dhs += pv[e][k];
+        const float tc = tanhf_(cc[e]);
+        const float dct = dci[e] + dhs * a[e].w * (1.f - tc * tc);
+        dg.x = dct * a[e].y * a[e].x * (1.f - a[e].x);
+        dg.y = dct * a[e].x * (1.f - a[e].y * a[e].y);
+        dg.z = dct * cpv[e] * a[e].z * (1.f - a[e].z);
+        dg.w = dhs * tc * a[e].w * (1.f - a[e].w);
+        dcn = dct * a[e].z;
+        if (jt == 0) *reinterpret_cast<float4*>(dgbuf + (size_t)rr[e] * DN + d * N4 + 4 * j) = dg;
+      } else if (jt == 0 && s < T) {
+        *reinterpret_cast<float4*>(dgbuf + ((size_t)s * Bp + b) * DN + d * N4 + 4 * j) = dg;
+      }
+      if (jt == 0) dcout[((size_t)d * Bp + b) * Hp + j] = dcn;
+      As[mt][0 * 32 + ju][b16] = dg.x;
+      As[mt][1 * 32 + ju][b16] = dg.y;
+      As[mt][2 * 32 + ju][b16] = dg.z;
+      As[mt][3 * 32 + ju][b16] = dg.w;
+    }
   }
   __syncthreads();
 
@@ -349,16 +403,25 @@ void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const floa
                           const float* gates, float* dgbuf, const float* cbuf, const float* dout, const float* dcin,
                           float* dcout, const int* seq_len, hipStream_t st) {
   dim3 grid((dm.Hp / 64) * (dm.Hp / 32), dm.D), block(256);
-  const int MT = dm.Bp / 16;
-#define NASR_BWD(MTV)                                                                                          \
-  hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV>), grid, block, 0, st, Ub, pin, pout, gates, dgbuf, cbuf, dout, \
-                     dcin, dcout, seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D)
-  switch (MT) {
-    case 1: NASR_BWD(1); break;
-    case 2: NASR_BWD(2); break;
-    case 3: NASR_BWD(3); break;
-    default: NASR_BWD(4); break;
+  const int MT = dm.Bp / 16, ksp = dm.Hp / 32;
+#define NASR_BWD(MTV, KV)                                                                                        \
+  hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV, KV>), grid, block, 0, st, Ub, pin, pout, gates, dgbuf, cbuf, \
+                     dout, dcin, dcout, seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D)
+#define NASR_BWD_K(MTV)                                   \
+  switch (ksp) {                                          \
+    case 2: NASR_BWD(MTV, 2); break;                      \
+    case 4: NASR_BWD(MTV, 4); break;                      \
+    case 8: NASR_BWD(MTV, 8); break;                      \
+    case 16: NASR_BWD(MTV, 16); break;                    \
+    default: NASR_BWD(MTV, 0); break;                     \
   }
+  switch (MT) {
+    case 1: NASR_BWD_K(1); break;
+    case 2: NASR_BWD_K(2); break;
+    case 3: NASR_BWD_K(3); break;
+    default: NASR_BWD_K(4); break;
+  }
+#undef NASR_BWD_K
 #undef NASR_BWD
 }
 
