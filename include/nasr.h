@@ -130,8 +130,24 @@ int nasr_compute_grads(nasr_handle h);          /* forward+CTC+backward on the r
 void* nasr_grad_device_ptr(nasr_handle h);
 int64_t nasr_grad_device_count(nasr_handle h);
 int nasr_apply_adam(nasr_handle h, float grad_scale); /* g*grad_scale, TF Adam, step += 1 (async) */
+/* copy the gradients out (TF order) / load externally reduced gradients (TF order) for nasr_apply_adam:
+ * the single-process form of average_gradients (several towers time-sliced on one GPU). */
+int nasr_get_grads(nasr_handle h, float* flat, int64_t n);
+int nasr_set_grads(nasr_handle h, const float* flat, int64_t n);
 int nasr_get_loss(nasr_handle h, float* loss_out);    /* synchronises; loss of last compute_grads */
 int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the resident batch */
+
+/* TensorFlowNetwork.train fetches mean_ler with every step (networks/tfnetwork.py:188-189): with
+ * step-decode enabled nasr_compute_grads / nasr_loss also run the greedy decoder on the step's logits
+ * (before the CTC gradient overwrites them); nasr_get_decoded returns that result (synchronises). */
+int nasr_set_step_decode(nasr_handle h, int enabled);
+int nasr_get_decoded(nasr_handle h, int32_t* ids_out /*[B,T']*/, int32_t* lens_out /*[B]*/);
+
+/* create_metric (networks/tfnetwork.py:66-70): mean over the batch of Levenshtein(hyp, truth)/len(truth)
+ * (tf.edit_distance normalize=True, Appendix A.7).  Host code, no GPU work.  hyp_ids [B,hyp_stride],
+ * labels [B,Lmax].  An empty truth gives inf for a non-empty hypothesis and 0 otherwise, as TF does. */
+int nasr_label_error_rate(const int32_t* hyp_ids, const int32_t* hyp_lens, int hyp_stride, const int32_t* labels,
+                          const int32_t* label_len, int Lmax, int B, float* ler_out);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 int nasr_set_profiling(nasr_handle h, int enabled); /* record HIP events around the phases */

@@ -58,12 +58,18 @@ void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, 
 }
 
 // ------------------------------------------------------------------ (2) alpha / beta
-// workspace layout: alpha[b][t][i][lane] with state s = lane*KS + i
+// workspace layout: alpha[b][t][i][lane] with state s = lane*KS + i, Tws = T + 4 rows per utterance.
+// The stored columns are RESCALED: alpha~(t,.) = alpha(t,.) - aoff[t], the offset (fp64, cumulative) being
+// bumped by the column maximum every 4 frames.  Raw fp32 log-domain values reach |1500| at T = 500, where one
+// ulp is 1.2e-4 and alpha+beta-logp (the posterior exponent) loses 3 digits; rescaled columns stay O(10).
+// The time loop runs in branch-free groups of 4 frames (loads clamped, updates selected) so the emission
+// gathers of the NEXT group are in flight behind counted waits while this group computes.
 template <int KS>
 __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     const float* __restrict__ logits, const float* __restrict__ logz, const int* __restrict__ labels,
     const int* __restrict__ label_len, const int* __restrict__ seq_len, float* __restrict__ alpha,
-    float* __restrict__ beta, float* __restrict__ nll, int Bp, int Cp, int C, int Lmax, int Tws) {
+    float* __restrict__ beta, double* __restrict__ aoff, double* __restrict__ boff, float* __restrict__ nll,
+    double* __restrict__ logp_out, int Bp, int Cp, int C, int Lmax, int Tws) {
   __shared__ float fin[64 * KS];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -82,15 +88,26 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
   const size_t rstride = (size_t)Bp * Cp;               // logits row stride between frames
   const float* lg = logits + (size_t)b * Cp;
   const float* lz = logz + b;
-  auto emit = [&](int t, float (&e)[KS]) {
+  auto emit = [&](int t, float (&e)[KS]) {               // t must be a valid frame (callers clamp)
     const float z = lz[(size_t)t * Bp];
 #pragma unroll
     for (int i = 0; i < KS; ++i) e[i] = act[i] ? lg[(size_t)t * rstride + ext[i]] - z : NEG;
   };
   float* ws = (w == 0 ? alpha : beta) + (size_t)b * Tws * KS * 64;
-  auto store = [&](int t, const float (&a)[KS]) {
+  double* off = (w == 0 ? aoff : boff) + (size_t)b * Tws;
+  auto store = [&](int t, const float (&a)[KS], double o) {
 #pragma unroll
     for (int i = 0; i < KS; ++i) ws[((size_t)t * KS + i) * 64 + lane] = a[i];
+    if (lane == 0) off[t] = o;
+  };
+  auto renorm = [&](float (&a)[KS], double& o) {
+    float m = a[0];
+#pragma unroll
+    for (int i = 1; i < KS; ++i) m = fmaxf(m, a[i]);
+    m = wave_max(m);
+#pragma unroll
+    for (int i = 0; i < KS; ++i) a[i] = a[i] > 0.5f * NEG ? a[i] - m : NEG;
+    o += (double)m;
   };
 
   if (w == 0) {
@@ -102,43 +119,39 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
       skip[i] = act[i] && s >= 2 && ext[i] != blank && ext[i] != e2;
     }
     float a[KS], e[4][KS];
+    double A = 0.0;
     emit(0, e[0]);
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       const int s = lane * KS + i;
       a[i] = (s < 2 && act[i]) ? e[0][i] : NEG;
     }
-    store(0, a);
+    store(0, a, A);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (1 + k < Tb) emit(1 + k, e[k]);
+    for (int k = 0; k < 4; ++k) emit(min(1 + k, Tb - 1), e[k]);
     for (int t0 = 1; t0 < Tb; t0 += 4) {
       float en[4][KS];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (t0 + 4 + k < Tb) emit(t0 + 4 + k, en[k]);
+      for (int k = 0; k < 4; ++k) emit(min(t0 + 4 + k, Tb - 1), en[k]);
+      renorm(a, A);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int t = t0 + k;
-        if (t < Tb) {
-          // neighbours from the previous lane
-          float p1 = __shfl_up(a[KS - 1], 1);
-          float p2 = (KS >= 2) ? __shfl_up(a[KS >= 2 ? KS - 2 : 0], 1) : __shfl_up(a[0], 2);
-          if (lane == 0) { p1 = NEG; p2 = NEG; }
-          if (KS == 1 && lane == 1) p2 = NEG;
-          float na[KS];
+        const bool live = t < Tb;
+        float p1 = __shfl_up(a[KS - 1], 1);
+        float p2 = (KS >= 2) ? __shfl_up(a[KS >= 2 ? KS - 2 : 0], 1) : __shfl_up(a[0], 2);
+        if (lane == 0) { p1 = NEG; p2 = NEG; }
+        if (KS == 1 && lane == 1) p2 = NEG;
+        float na[KS];
 #pragma unroll
-          for (int i = 0; i < KS; ++i) {
-            const float x1 = (i >= 1) ? a[i - 1] : p1;
-            const float x2 = (i >= 2) ? a[i - 2] : (i == 1 ? p1 : p2);
-            // note: for i == 1 the s-2 neighbour is the previous lane's LAST state (p1) only when KS == 1 is
-            // excluded; with KS >= 2 state s-2 of i==1 is previous lane's a[KS-1]
-            na[i] = e[k][i] + lse3(a[i], x1, skip[i] ? x2 : NEG);
-          }
-#pragma unroll
-          for (int i = 0; i < KS; ++i) a[i] = act[i] ? na[i] : NEG;
-          store(t, a);
+        for (int i = 0; i < KS; ++i) {
+          const float x1 = (i >= 1) ? a[i >= 1 ? i - 1 : 0] : p1;
+          const float x2 = (i >= 2) ? a[i >= 2 ? i - 2 : 0] : (i == 1 ? p1 : p2);
+          na[i] = e[k][i] + lse3(a[i], x1, skip[i] ? x2 : NEG);
         }
+#pragma unroll
+        for (int i = 0; i < KS; ++i) a[i] = live ? (act[i] ? na[i] : NEG) : a[i];
+        store(t, a, A);              // rows Tb..Tb+2 of the workspace take dead copies (Tws = T+4)
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -147,11 +160,13 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     }
 #pragma unroll
     for (int i = 0; i < KS; ++i) fin[lane * KS + i] = a[i];
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave visible to itself
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     if (lane == 0) {
       const float x = fin[S - 1];
       const float y = S > 1 ? fin[S - 2] : NEG;
-      nll[b] = -lse3(x, y, NEG);
+      const double lp = A + (double)lse3(x, y, NEG);
+      logp_out[b] = lp;
+      nll[b] = (float)(-lp);
     }
   } else {
     // ---------------- beta, backward in time (excludes the emission at t)
@@ -162,43 +177,42 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
       skip[i] = (s + 2 < S) && e2 != blank && e2 != ext[i];
     }
     float bt[KS], e[4][KS];
+    double Bo = 0.0;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       const int s = lane * KS + i;
       bt[i] = (act[i] && (s == S - 1 || s == S - 2)) ? 0.f : NEG;
     }
-    store(Tb - 1, bt);
+    store(Tb - 1, bt, Bo);
     // e[k] holds the emission of frame (t+1) for the k-th step of a group
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (Tb - 1 - k >= 1) emit(Tb - 1 - k, e[k]);
+    for (int k = 0; k < 4; ++k) emit(max(Tb - 1 - k, 0), e[k]);
     for (int t0 = Tb - 2; t0 >= 0; t0 -= 4) {
       float en[4][KS];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (t0 - 4 - k + 1 >= 1) emit(t0 - 4 - k + 1, en[k]);
+      for (int k = 0; k < 4; ++k) emit(max(t0 - 4 - k + 1, 0), en[k]);
+      renorm(bt, Bo);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int t = t0 - k;
-        if (t >= 0) {
-          float bb[KS];
+        const bool live = t >= 0;
+        float bb[KS];
 #pragma unroll
-          for (int i = 0; i < KS; ++i) bb[i] = act[i] ? bt[i] + e[k][i] : NEG;
-          float n1 = __shfl_down(bb[0], 1);
-          float n2 = (KS >= 2) ? __shfl_down(bb[KS >= 2 ? 1 : 0], 1) : __shfl_down(bb[0], 2);
-          if (lane == 63) { n1 = NEG; n2 = NEG; }
-          if (KS == 1 && lane == 62) n2 = NEG;
-          float nb[KS];
+        for (int i = 0; i < KS; ++i) bb[i] = act[i] ? bt[i] + e[k][i] : NEG;
+        float n1 = __shfl_down(bb[0], 1);
+        float n2 = (KS >= 2) ? __shfl_down(bb[KS >= 2 ? 1 : 0], 1) : __shfl_down(bb[0], 2);
+        if (lane == 63) { n1 = NEG; n2 = NEG; }
+        if (KS == 1 && lane == 62) n2 = NEG;
+        float nb[KS];
 #pragma unroll
-          for (int i = 0; i < KS; ++i) {
-            const float x1 = (i + 1 < KS) ? bb[i + 1 < KS ? i + 1 : 0] : n1;
-            const float x2 = (i + 2 < KS) ? bb[i + 2 < KS ? i + 2 : 0] : (i + 1 < KS ? n1 : n2);
-            nb[i] = lse3(bb[i], x1, skip[i] ? x2 : NEG);
-          }
-#pragma unroll
-          for (int i = 0; i < KS; ++i) bt[i] = act[i] ? nb[i] : NEG;
-          store(t, bt);
+        for (int i = 0; i < KS; ++i) {
+          const float x1 = (i + 1 < KS) ? bb[i + 1 < KS ? i + 1 : 0] : n1;
+          const float x2 = (i + 2 < KS) ? bb[i + 2 < KS ? i + 2 : 0] : (i + 1 < KS ? n1 : n2);
+          nb[i] = lse3(bb[i], x1, skip[i] ? x2 : NEG);
         }
+#pragma unroll
+        for (int i = 0; i < KS; ++i) bt[i] = live ? (act[i] ? nb[i] : NEG) : bt[i];
+        if (live) store(t, bt, Bo);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -209,11 +223,11 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
 }
 
 void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,
-                           const int* label_len, const int* seq_len, float* alpha, float* beta, float* nll,
-                           hipStream_t st) {
+                           const int* label_len, const int* seq_len, float* alpha, float* beta, double* aoff,
+                           double* boff, float* nll, double* logp, hipStream_t st) {
 #define NASR_AB(K)                                                                                              \
   hipLaunchKernelGGL((ctc_alpha_beta_kernel<K>), dim3(d.B), dim3(128), 0, st, logits, logz, labels, label_len, \
-                     seq_len, alpha, beta, nll, d.Bp, d.Cp, d.C, d.Lmax, d.Tws)
+                     seq_len, alpha, beta, aoff, boff, nll, logp, d.Bp, d.Cp, d.C, d.Lmax, d.Tws)
   switch (d.KS) {
     case 1: NASR_AB(1); break;
     case 2: NASR_AB(2); break;
@@ -235,7 +249,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logit
                                                        const int* __restrict__ label_len,
                                                        const int* __restrict__ seq_len,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                       const float* __restrict__ nll, float scale, int Tp, int B,
+                                                       const double* __restrict__ aoff, const double* __restrict__ boff,
+                                                       const double* __restrict__ logp, float scale, int Tp, int B,
                                                        int Bp, int C, int Cp, int Lmax, int KS, int Tws) {
   extern __shared__ __attribute__((aligned(16))) float bins_all[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logit
   float* bins = bins_all + (size_t)wv * Cp;
   for (int c = lane; c < Cp; c += 64) bins[c] = 0.f;
   const int L = label_len[b], S = 2 * L + 1;
-  const float logp = -nll[b];
+  const float coff = (float)(aoff[(size_t)b * Tws + t] + boff[(size_t)b * Tws + t] - logp[b]);
   const int* lab = labels + (size_t)b * Lmax;
   const float* al = alpha + ((size_t)b * Tws + t) * KS * 64;
   const float* be = beta + ((size_t)b * Tws + t) * KS * 64;
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logit
     const int s = lane * KS + i;
     if (s < S) {
       const int k = (s & 1) ? lab[s >> 1] : C - 1;
-      const float wgt = __expf(al[i * 64 + lane] + be[i * 64 + lane] - logp);
+      const float wgt = __expf(al[i * 64 + lane] + be[i * 64 + lane] + coff);
       atomicAdd(&bins[k], wgt);
     }
   }
@@ -273,13 +288,13 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logit
 }
 
 void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* labels, const int* label_len,
-                     const int* seq_len, const float* alpha, const float* beta, const float* nll, float scale,
-                     hipStream_t st) {
+                     const int* seq_len, const float* alpha, const float* beta, const double* aoff,
+                     const double* boff, const double* logp, float scale, hipStream_t st) {
   const int rows = d.Tp * d.Bp;
   const int rpb = d.Cp <= 2048 ? 4 : 1;
   hipLaunchKernelGGL(ctc_grad_kernel, dim3((rows + rpb - 1) / rpb), dim3(64 * rpb), (size_t)rpb * d.Cp * 4, st, logits,
-                     logz, labels, label_len, seq_len, alpha, beta, nll, scale, d.Tp, d.B, d.Bp, d.C, d.Cp, d.Lmax, d.KS,
-                     d.Tws);
+                     logz, labels, label_len, seq_len, alpha, beta, aoff, boff, logp, scale, d.Tp, d.B, d.Bp, d.C, d.Cp,
+                     d.Lmax, d.KS, d.Tws);
 }
 
 // mean of n floats (n small: the batch), fixed order

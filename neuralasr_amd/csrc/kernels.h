@@ -50,16 +50,16 @@ struct CtcDims {
   int Tp;      // logit frames T'
   int B, Bp, C, Cp, Lmax;
   int KS;      // states per lane: ceil((2*Lmax+1)/64)
-  int Tws;     // time extent of the alpha/beta workspace (max seq_len)
+  int Tws;     // rows of the alpha/beta workspace per utterance (T + 4)
 };
 void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, float* logz, hipStream_t st);
 void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,
-                           const int* label_len, const int* seq_len, float* alpha, float* beta, float* nll,
-                           hipStream_t st);
+                           const int* label_len, const int* seq_len, float* alpha, float* beta, double* aoff,
+                           double* boff, float* nll, double* logp, hipStream_t st);
 // in place: logits -> d(mean nll)/dlogits
 void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* labels, const int* label_len,
-                     const int* seq_len, const float* alpha, const float* beta, const float* nll, float scale,
-                     hipStream_t st);
+                     const int* seq_len, const float* alpha, const float* beta, const double* aoff,
+                     const double* boff, const double* logp, float scale, hipStream_t st);
 void launch_mean(const float* v, int n, float* out, hipStream_t st);
 void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, int* argmax_ws, int* ids, int* lens,
                    hipStream_t st);

@@ -3,6 +3,7 @@
 // interfaces each entry point replaces and DESIGN.md for the layout.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -92,12 +93,13 @@ struct nasr_ctx {
   int64_t frames = 0;
   std::vector<int32_t> h_seq;
 
-  DevBuf feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, logits, logz, alpha, beta, nll, loss, seq, labels, lablen,
+  DevBuf feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
       rowmap, slabs, csws, amax, ids, lens, stage;
   std::vector<DevBuf> gates, outb, cbuf;
 
   // graphs
   bool graph_mode = true;
+  bool step_decode = false, have_decoded = false;
   std::map<GraphKey, hipGraphExec_t> graphs;
 
   // profiling
@@ -306,8 +308,11 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
   const int KSa = KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations
-  ok &= h->alpha.ensure((size_t)B * T * KSa * 64 * 4, &grew);
-  ok &= h->beta.ensure((size_t)B * T * KSa * 64 * 4, &grew);
+  ok &= h->alpha.ensure((size_t)B * (T + 4) * KSa * 64 * 4, &grew);
+  ok &= h->beta.ensure((size_t)B * (T + 4) * KSa * 64 * 4, &grew);
+  ok &= h->aoff.ensure((size_t)B * (T + 4) * 8, &grew);
+  ok &= h->boff.ensure((size_t)B * (T + 4) * 8, &grew);
+  ok &= h->logp.ensure((size_t)Bp * 8, &grew);
   ok &= h->nll.ensure((size_t)Bp * 4, &grew);
   ok &= h->loss.ensure(16, &grew);
   ok &= h->seq.ensure((size_t)Bp * 4, &grew);
@@ -410,6 +415,7 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
   h->resident = true;
   h->have_grads = false;
   h->have_fwd = false;
+  h->have_decoded = false;
   return NASR_OK;
 }
 
@@ -515,7 +521,7 @@ int forward(nasr_ctx* h) {
 CtcDims ctc_dims(nasr_ctx* h) {
   CtcDims d;
   d.Tp = h->Tp; d.B = h->B; d.Bp = h->Bp; d.C = h->C; d.Cp = h->Cp; d.Lmax = std::max(h->Lmax, 1);
-  d.KS = h->KS; d.Tws = h->T;
+  d.KS = h->KS; d.Tws = h->T + 4;
   return d;
 }
 
@@ -524,8 +530,14 @@ int ctc_forward(nasr_ctx* h) {
   const CtcDims d = ctc_dims(h);
   launch_ctc_logz(d, h->logits.as<float>(), h->seq.as<int>(), h->logz.as<float>(), h->st);
   launch_ctc_alpha_beta(d, h->logits.as<float>(), h->logz.as<float>(), h->labels.as<int>(), h->lablen.as<int>(),
-                        h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->nll.as<float>(), h->st);
+                        h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->aoff.as<double>(),
+                        h->boff.as<double>(), h->nll.as<float>(), h->logp.as<double>(), h->st);
   launch_mean(h->nll.as<float>(), h->B, h->loss.as<float>(), h->st);
+  if (h->step_decode) {
+    launch_greedy(d, h->logits.as<float>(), h->seq.as<int>(), h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
+                  h->st);
+    h->have_decoded = true;
+  }
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
 }
@@ -538,8 +550,8 @@ int backward(nasr_ctx* h) {
     PhaseScope ps(h, PH_PROJCTC);
     const CtcDims d = ctc_dims(h);
     launch_ctc_grad(d, h->logits.as<float>(), h->logz.as<float>(), h->labels.as<int>(), h->lablen.as<int>(),
-                    h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->nll.as<float>(),
-                    1.f / (float)h->B, h->st);
+                    h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->aoff.as<double>(),
+                    h->boff.as<double>(), h->logp.as<double>(), 1.f / (float)h->B, h->st);
     HIPCHK(h, hipGetLastError());
   }
   {
@@ -720,7 +732,7 @@ int nasr_destroy(nasr_handle h) {
   for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub})
     if (p) (void)hipFree(p);
   for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->logits, &h->logz,
-                    &h->alpha, &h->beta, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
+                    &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
     b->release();
   for (auto& b : h->gates) b.release();
@@ -864,6 +876,55 @@ int nasr_apply_adam(nasr_handle h, float grad_scale) {
   return NASR_OK;
 }
 
+int nasr_get_grads(nasr_handle h, float* flat, int64_t n) {
+  if (!h || !flat) return NASR_ERR_ARG;
+  if (n != h->np_tf) return h->fail(NASR_ERR_ARG, "nasr_get_grads: wrong length");
+  if (!h->have_grads) return h->fail(NASR_ERR_STATE, "nasr_get_grads without gradients");
+  HIPCHK(h, hipSetDevice(h->device));
+  return gather_from_device(h, h->G, flat);
+}
+
+int nasr_set_grads(nasr_handle h, const float* flat, int64_t n) {
+  if (!h || !flat) return NASR_ERR_ARG;
+  if (n != h->np_tf) return h->fail(NASR_ERR_ARG, "nasr_set_grads: wrong length");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = scatter_to_device(h, flat, h->G);
+  if (rc) return rc;
+  h->have_grads = true;
+  return NASR_OK;
+}
+
+int nasr_label_error_rate(const int32_t* hyp_ids, const int32_t* hyp_lens, int hyp_stride, const int32_t* labels,
+                          const int32_t* label_len, int Lmax, int B, float* ler_out) {
+  if (!hyp_ids || !hyp_lens || !labels || !label_len || !ler_out || B < 1) return NASR_ERR_ARG;
+  double acc = 0.0;
+  std::vector<int> row;
+  for (int b = 0; b < B; ++b) {
+    const int n = hyp_lens[b], m = label_len[b];
+    const int32_t* hy = hyp_ids + (size_t)b * hyp_stride;
+    const int32_t* tr = labels + (size_t)b * Lmax;
+    if (m == 0) {
+      acc += n > 0 ? INFINITY : 0.0;
+      continue;
+    }
+    row.resize((size_t)m + 1);
+    for (int j = 0; j <= m; ++j) row[j] = j;
+    for (int i = 1; i <= n; ++i) {
+      int prev = row[0];
+      row[0] = i;
+      for (int j = 1; j <= m; ++j) {
+        const int cur = row[j];
+        const int sub = prev + (hy[i - 1] != tr[j - 1] ? 1 : 0);
+        row[j] = std::min(std::min(row[j] + 1, row[j - 1] + 1), sub);
+        prev = cur;
+      }
+    }
+    acc += (double)row[m] / (double)m;
+  }
+  *ler_out = (float)(acc / B);
+  return NASR_OK;
+}
+
 int nasr_get_loss(nasr_handle h, float* loss_out) {
   if (!h || !loss_out) return NASR_ERR_ARG;
   HIPCHK(h, hipMemcpyAsync(loss_out, h->loss.p, 4, hipMemcpyDeviceToHost, h->st));
@@ -947,6 +1008,21 @@ int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(lens_out, h->lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipMemcpyAsync(ids_out, h->ids.p, (size_t)B * h->Tp * 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return NASR_OK;
+}
+
+int nasr_set_step_decode(nasr_handle h, int enabled) {
+  if (!h) return NASR_ERR_ARG;
+  h->step_decode = enabled != 0;
+  return NASR_OK;
+}
+
+int nasr_get_decoded(nasr_handle h, int32_t* ids_out, int32_t* lens_out) {
+  if (!h || !ids_out || !lens_out) return NASR_ERR_ARG;
+  if (!h->have_decoded) return h->fail(NASR_ERR_STATE, "nasr_get_decoded: no decoded step (enable nasr_set_step_decode)");
+  HIPCHK(h, hipMemcpyAsync(lens_out, h->lens.p, (size_t)h->B * 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(ids_out, h->ids.p, (size_t)h->B * h->Tp * 4, hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipStreamSynchronize(h->st));
   return NASR_OK;
 }

@@ -1,0 +1,94 @@
+"""Batch reader over a .scp list of pickled AudioSample files (reference: dataset.py:12-91).
+Same semantics: sequential batches of config.batch_size files, features and labels padded with the
+padding id (0) to the batch maximum, the tail batch filled by re-loading the last file, optional
+rand_shift roll-and-crop augmentation; returns (ndarray f32 [B,T,F], ndarray i32 [B,Lmax],
+list of 0-d np.int32, list of int)."""
+import io
+import os
+import pickle
+
+import numpy as np
+
+from .audiosample import AudioSample
+
+_NUMPY_OK = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+             ('numpy', 'ndarray'), ('numpy', 'dtype'), ('numpy.core.multiarray', 'scalar'),
+             ('numpy._core.multiarray', 'scalar'), ('numpy._core.numeric', '_frombuffer'),
+             ('numpy.core.numeric', '_frombuffer'),
+             # byte-string / plain-object reconstruction helpers pickle protocols 2-5 emit (no side effects)
+             ('_codecs', 'encode'), ('copyreg', '_reconstructor'), ('copy_reg', '_reconstructor'),
+             ('builtins', 'object'), ('__builtin__', 'object')}
+
+
+class _SampleUnpickler(pickle.Unpickler):
+    """Resolves `audiosample.AudioSample` (the module path preprocess_mfcc.py pickled) to our class and
+    allows nothing beyond the NumPy array reconstructors: a .pkl is data, not code."""
+
+    def find_class(self, module, name):
+        if name == 'AudioSample' and module.split('.')[-1] == 'audiosample':
+            return AudioSample
+        if (module, name) in _NUMPY_OK:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError('refusing to load %s.%s from a sample file' % (module, name))
+
+
+class DataSet:
+    def __init__(self, filename, config):
+        self.filename = filename
+        self.config = config
+        self.padding_id = config.symbols.get_padding_id()
+        self.index = 0
+        root = os.path.dirname(self.filename)
+        with open(self.filename, 'r') as fh:
+            self.X = [os.path.join(root, line.strip()) for line in fh.readlines()]
+
+    def augment_mfcc(self, mfcc):
+        shift = self.config.rand_shift
+        r = np.random.randint(-shift, shift)
+        mfcc = np.roll(mfcc, r, axis=0)
+        if r > 0:
+            return mfcc[r:, :]
+        if r < 0:
+            return mfcc[:r, :]
+        return mfcc
+
+    def load_pkl(self, pklfilename):
+        with open(pklfilename, 'rb') as fh:
+            sample = _SampleUnpickler(io.BytesIO(fh.read())).load()
+        if self.config.rand_shift > 0:
+            sample.mfcc = self.augment_mfcc(sample.mfcc)
+        return sample.mfcc, sample.labels, np.asarray(sample.mfcc.shape[0], dtype=np.int32), sample.labels.shape[0]
+
+    def reset_epoch(self):
+        self.index = 0
+
+    def has_more_batches(self):
+        return self.index < len(self.X)
+
+    def get_next_batch(self):
+        bs = self.config.batch_size
+        items = [self.load_pkl(self.X[self.index])]
+        self.index += 1
+        while self.index % bs > 0:
+            if self.index >= len(self.X):
+                if len(items) == bs:
+                    break
+                self.index -= 1          # tail batch: keep re-loading the last file until it is full
+            items.append(self.load_pkl(self.X[self.index]))
+            self.index += 1
+        max_time = max(m.shape[0] for m, _, _, _ in items)
+        max_label = max(n for _, _, _, n in items)
+        pad = self.padding_id
+        mfccs = [np.pad(m, ((0, max_time - m.shape[0]), (0, 0)), 'constant', constant_values=(pad, pad))
+                 for m, _, _, _ in items]
+        labels = [np.pad(l, (0, max_label - n), 'constant', constant_values=(pad, pad)) for _, l, _, n in items]
+        return np.asarray(mfccs), np.asarray(labels), [s for _, _, s, _ in items], [n for _, _, _, n in items]
+
+    def get_feature_shape(self):
+        return [self.config.batch_size, None, self.config.feature_size]
+
+    def get_label_shape(self):
+        return [self.config.batch_size, None, 1]
+
+    def get_num_of_sample(self):
+        return len(self.X)

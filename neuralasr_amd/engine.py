@@ -167,6 +167,43 @@ class Engine:
     def apply_adam(self, grad_scale=1.0):
         self._ck(self.lib.nasr_apply_adam(self.h, float(grad_scale)))
 
+    def get_grads(self):
+        g = np.empty(self.param_count, np.float32)
+        self._ck(self.lib.nasr_get_grads(self.h, _fp(g), g.size))
+        return g
+
+    def set_grads(self, flat):
+        flat = _f32(flat).ravel()
+        self._ck(self.lib.nasr_set_grads(self.h, _fp(flat), flat.size))
+
+    def label_error_rate(self, hyps, labels, label_len):
+        """mean over the batch of edit_distance(hyp, truth)/len(truth) (networks/tfnetwork.py:66-70)."""
+        B = len(hyps)
+        stride = max(1, max((len(h) for h in hyps), default=1))
+        ids = np.zeros((B, stride), np.int32)
+        lens = np.zeros(B, np.int32)
+        for b, hy in enumerate(hyps):
+            lens[b] = len(hy)
+            ids[b, :len(hy)] = hy
+        labels = _i32(labels).reshape(B, -1)
+        ll = _i32(np.asarray([int(x) for x in label_len]))
+        out = c_float()
+        rc = self.lib.nasr_label_error_rate(_ip(ids), _ip(lens), stride, _ip(labels), _ip(ll), labels.shape[1], B,
+                                            byref(out))
+        if rc != 0:
+            raise _lib.NasrError(rc, 'nasr_label_error_rate: bad arguments')
+        return float(out.value)
+
+    def set_step_decode(self, on):
+        self._ck(self.lib.nasr_set_step_decode(self.h, int(bool(on))))
+
+    def get_decoded(self, B, T):
+        Tp = self.logit_frames(T)
+        ids = np.zeros((B, Tp), np.int32)
+        lens = np.zeros(B, np.int32)
+        self._ck(self.lib.nasr_get_decoded(self.h, _ip(ids), _ip(lens)))
+        return [ids[b, :lens[b]].tolist() for b in range(B)]
+
     def get_loss(self):
         loss = c_float()
         self._ck(self.lib.nasr_get_loss(self.h, byref(loss)))

@@ -1,0 +1,178 @@
+"""HipNetwork — the counterpart of TensorFlowNetwork (reference: networks/tfnetwork.py:13-190): numpy-in /
+numpy-out train / validate / evaluate / decode, checkpoints, and data-parallel training, with every
+arithmetic step in the HIP library behind include/nasr.h (no TensorFlow, no CPU fallback).
+
+Differences from the reference that a caller can observe, all deliberate and documented in DESIGN.md:
+  * the decoder behind `mean_ler`, evaluate() and decode() is the greedy CTC decoder the reference names in
+    the comment at tfnetwork.py:62-63, not beam search width 100 (a "next" row of SURVEY.md §8f);
+  * num_gpus > 1 means one process per GPU (torch.distributed.run); inside a single process the towers are
+    time-sliced on one GPU with the same split / averaging arithmetic;
+  * checkpoints are `model-<step>.npz` (flat fp32 params + Adam m, v + step) with TF Saver's cadence and
+    keep-5 policy, not TF's format."""
+import glob
+import json
+import os
+import shutil
+
+import numpy as np
+
+from ..engine import Engine
+from ..parallel import Collective, take_shard
+from .network import Network
+
+
+def _glorot_init(tensors, seed):
+    """Default TF initialisers the reference relies on: glorot-uniform LSTM kernels, zero biases,
+    xavier-normal W (networks/bilstm_ctc_net.py:35-36), zero b.  TF's own seeded stream
+    (tf.set_random_seed(1), tfnetwork.py:19) is not reproducible outside TF."""
+    rs = np.random.RandomState(seed)
+    chunks = []
+    for name, _, rows, cols in tensors:
+        if name.endswith('kernel'):
+            lim = np.sqrt(6.0 / (rows + cols))
+            chunks.append(rs.uniform(-lim, lim, size=rows * cols))
+        elif name == 'W':
+            chunks.append(rs.randn(rows * cols) * np.sqrt(2.0 / (rows + cols)))
+        else:
+            chunks.append(np.zeros(rows * cols))
+    return np.concatenate(chunks).astype(np.float32)
+
+
+class HipNetwork(Network):
+    # model shape; subclasses override (the reference hard-codes these as locals of create_network)
+    num_hidden = 500
+    num_layers = 1
+    bidirectional = True
+    merge = 'stack_reshape'
+    keep_checkpoints = 5                     # tf.train.Saver() default max_to_keep
+
+    def __init__(self, config, fortraining=False):
+        Network.__init__(self)
+        self.fortraining = fortraining
+        self.config = config
+        self.num_classes = config.symbols.counter
+        self.coll = Collective()
+        device = int(os.environ.get('LOCAL_RANK', '0')) if self.coll.world > 1 else 0
+        stream = None
+        if self.coll.world > 1:
+            import torch
+            torch.cuda.set_device(device)
+            stream = torch.cuda.current_stream().cuda_stream
+        self.logger.info('Initializing network for %s.' % ('training' if fortraining else 'inference'))
+        self.engine = Engine(config.feature_size, self.num_hidden, self.num_layers, self.bidirectional, self.merge,
+                             self.num_classes, learning_rate=config.learningrate, device_id=device, stream=stream)
+        self.engine.set_step_decode(True)
+        self.engine.set_params(_glorot_init(self.engine.tensors(), seed=1))
+        self._grad_tensor = None
+        self.global_step = self.config.start_step
+        self.load_checkpoint(self.global_step if fortraining else 1, self.config.model_dir)
+        if fortraining and self.coll.rank == 0:
+            self.write_config()
+            self.config.symbols.write(os.path.join(self.config.model_dir, os.path.basename(self.config.sym_file)))
+
+    # ------------------------------------------------------------------ per-model hook
+    def create_network(self, features, labels, seq_len, labels_len, num_classes, is_training):
+        """(logits [T',B,C], loss, decoded ids per utterance, None, mean LER) for a batch
+        (reference: networks/bilstm_ctc_net.py:10-52 returns the same five graph nodes)."""
+        logits = self.engine.forward(features, seq_len)
+        loss, _ = self.engine.loss(features, seq_len, labels, labels_len)
+        hyps = self.engine.get_decoded(len(seq_len), np.asarray(features).shape[1])
+        ler = self.engine.label_error_rate(hyps, labels, labels_len)
+        return logits, loss, hyps, None, ler
+
+    # ------------------------------------------------------------------ checkpoints
+    def _ckpt_files(self, model_dir):
+        files = glob.glob(os.path.join(model_dir, 'model-*.npz'))
+        return sorted(files, key=lambda f: int(os.path.basename(f)[6:-4]))
+
+    def load_checkpoint(self, start_epoch, model_dir):
+        if start_epoch > 0:
+            self.logger.info('Restoring checkpoint: ' + model_dir)
+            files = self._ckpt_files(model_dir)
+            if not files:
+                raise FileNotFoundError('no checkpoint (model-<step>.npz) in ' + model_dir)
+            with np.load(files[-1]) as z:
+                self.engine.set_params(z['params'])
+                self.engine.set_adam_state(z['adam_m'], z['adam_v'], int(z['step']))
+            self.logger.info('Done Restoring checkpoint: ' + files[-1])
+        elif self.coll.rank == 0:
+            if os.path.exists(model_dir):
+                shutil.rmtree(model_dir)
+            os.makedirs(model_dir)
+
+    def write_config(self):
+        dst = os.path.join(self.config.model_dir, os.path.basename(self.config.configfile))
+        if os.path.exists(dst):
+            self.logger.warning('Not overwriting. Config file already exists: ' + dst)
+        else:
+            self.config.write(dst)
+
+    def save_checkpoint(self):
+        if self.coll.rank != 0:
+            return
+        m, v, step = self.engine.get_adam_state()
+        path = os.path.join(self.config.model_dir, 'model-%d.npz' % self.global_step)
+        np.savez(path, params=self.engine.get_params(), adam_m=m, adam_v=v, step=np.int64(step),
+                 meta=json.dumps({'hidden': self.num_hidden, 'layers': self.num_layers,
+                                  'bidirectional': self.bidirectional, 'merge': self.merge,
+                                  'classes': self.num_classes, 'feature_size': self.config.feature_size}))
+        for old in self._ckpt_files(self.config.model_dir)[:-self.keep_checkpoints]:
+            os.remove(old)
+
+    # ------------------------------------------------------------------ numpy-in / numpy-out API
+    def _towers(self):
+        """(n, owned tower indices): one tower per process under torch.distributed, otherwise all
+        num_gpus towers time-sliced in this process."""
+        n = max(1, int(self.config.num_gpus)) if self.fortraining else 1
+        if self.coll.world > 1:
+            if n != self.coll.world:
+                raise ValueError('config num_gpus=%d but %d processes were launched' % (n, self.coll.world))
+            return n, [self.coll.rank]
+        return n, list(range(n))
+
+    def _loss_ler(self, mfccs, labels, seq_len, labels_len):
+        loss, _ = self.engine.loss(mfccs, seq_len, labels, labels_len)
+        hyps = self.engine.get_decoded(len(seq_len), np.asarray(mfccs).shape[1])
+        return loss, self.engine.label_error_rate(hyps, labels, labels_len), hyps
+
+    def train(self, mfccs, labels, seq_len, labels_len):
+        self.global_step += 1
+        n, mine = self._towers()
+        losses, lers, gsum = [], [], None
+        for k in mine:
+            f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, k)
+            self.engine.upload_batch(f, s, l, ll)
+            self.engine.compute_grads()
+            losses.append(self.engine.get_loss())
+            lers.append(self.engine.label_error_rate(self.engine.get_decoded(len(s), f.shape[1]), l, ll))
+            if len(mine) > 1:
+                g = self.engine.get_grads().astype(np.float64)
+                gsum = g if gsum is None else gsum + g
+        if len(mine) > 1:                       # towers time-sliced on one GPU: host-side sum
+            self.engine.set_grads((gsum / n).astype(np.float32))
+            self.engine.apply_adam(1.0)
+        elif self.coll.world > 1:               # one tower per GPU: RCCL all-reduce of the flat buffer
+            if self._grad_tensor is None:
+                self._grad_tensor = self.engine.grad_tensor()
+            self.coll.all_reduce_sum_(self._grad_tensor)
+            self.engine.apply_adam(1.0 / n)
+        else:
+            self.engine.apply_adam(1.0)
+        loss, ler = float(np.mean(losses)), float(np.mean(lers))
+        if self.coll.world > 1:
+            loss, ler = self.coll.mean_scalars([loss, ler])
+        return np.float32(loss), np.float32(ler)
+
+    def validate(self, mfccs, labels, seq_len, labels_len):
+        loss, ler, _ = self._loss_ler(mfccs, labels, seq_len, labels_len)
+        return [np.float32(loss), np.float32(ler)]
+
+    def evaluate(self, mfccs, labels, seq_len, labels_len):
+        loss, ler, hyps = self._loss_ler(mfccs, labels, seq_len, labels_len)
+        # SparseTensorValue.values: every utterance's ids concatenated (tfnetwork.py:176-177)
+        flat = np.asarray([i for h in hyps for i in h], dtype=np.int64)
+        return flat, np.float32(loss), np.float32(ler)
+
+    def decode(self, mfccs, seq_len):
+        hyps = self.engine.greedy_decode(mfccs, seq_len)
+        return np.asarray([i for h in hyps for i in h], dtype=np.int64)

@@ -1,0 +1,58 @@
+"""Data-parallel sharding: the reference's in-graph tower replication (make_parallel + average_gradients,
+networks/tfnetwork.py:72-140) re-expressed as ONE SHARD PER GPU / PROCESS with a sum all-reduce of one flat
+fp32 gradient buffer and the 1/n folded into the optimiser step.
+
+  * the global batch (config.batch_size = per-GPU batch x num_gpus, config.py:35-36) is cut into n equal
+    contiguous chunks on axis 0 (tf.split semantics); every shard keeps the GLOBAL max T, so the literal
+    BiLstmCTCNet's stack-reshape index map (a function of the shard's B and of T) is what the
+    reference's towers see;
+  * loss / LER reported = mean of the shard means (tfnetwork.py:135-136);
+  * gradient = mean over shards of each shard's gradient of its shard-mean loss (tfnetwork.py:72-86).
+
+The collective is torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
+tests); torch is plumbing only."""
+import numpy as np
+
+
+def shard_bounds(global_batch, world, rank):
+    """Rows [lo, hi) of the global batch that tower `rank` of `world` owns (tf.split, axis 0)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError('bad world/rank %r/%r' % (world, rank))
+    if global_batch % world:
+        raise ValueError('global batch %d does not split evenly over %d towers' % (global_batch, world))
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def take_shard(mfccs, labels, seq_len, labels_len, world, rank):
+    lo, hi = shard_bounds(len(seq_len), world, rank)
+    labels = np.asarray(labels)
+    return (np.asarray(mfccs)[lo:hi], labels[lo:hi] if labels.ndim else labels, list(seq_len[lo:hi]),
+            list(labels_len[lo:hi]) if labels_len is not None else None)
+
+
+class Collective:
+    """Thin view of the process group: world size, rank, sum-all-reduce of tensors / python floats."""
+
+    def __init__(self):
+        try:
+            import torch.distributed as dist
+            self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        except Exception:
+            self.dist = None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+
+    def all_reduce_sum_(self, tensor):
+        if self.dist:
+            self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
+        return tensor
+
+    def mean_scalars(self, values, device=None):
+        """mean over ranks of a few python floats (loss, ler): the reduce_mean of tfnetwork.py:135-136."""
+        if not self.dist:
+            return [float(v) for v in values]
+        import torch
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(x) / self.world for x in t.tolist()]

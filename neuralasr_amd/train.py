@@ -1,0 +1,66 @@
+"""Training loop (reference: train.py:14-63): epochs x batches, cumulative wall time, checkpoint + log +
+one validation batch every report_step, same log-line formats.
+
+  python -m neuralasr_amd.train <config>
+  python -m torch.distributed.run --nproc-per-node N -m neuralasr_amd.train <config>   # num_gpus = N"""
+import argparse
+import os
+import time
+
+from .config import Config
+from .dataset import DataSet
+from .logger import get_logger
+
+logger = get_logger()
+
+
+def train_model(dataTrain, datavalid, config):
+    logger.info('Batch Dimensions: ' + str(dataTrain.get_feature_shape()))
+    logger.info('Label Dimensions: ' + str(dataTrain.get_label_shape()))
+    network = config.load_network(fortraining=True)
+    spent, loss_sum, ler_sum = 0.0, 0.0, 0.0     # train_time_sec is never reset (train.py:20,26,34)
+    for _ in range(config.epochs):
+        while dataTrain.has_more_batches():
+            t0 = time.time()
+            mfccs, labels, seq_len, labels_len = dataTrain.get_next_batch()
+            loss, mean_ler = network.train(mfccs, labels, seq_len, labels_len)
+            spent += time.time() - t0
+            loss_sum += loss
+            ler_sum += mean_ler
+            if network.global_step % config.report_step == 0:
+                network.save_checkpoint()
+                logger.info('Step: %04d' % network.global_step + ', cost = %.4f' % (loss_sum / config.report_step) +
+                            ', ler = %.4f' % (ler_sum / config.report_step) + ', time = %.4f' % spent)
+                loss_sum = ler_sum = 0.0
+                if datavalid:
+                    if not datavalid.has_more_batches():
+                        datavalid.reset_epoch()
+                    vm, vl, vs, vll = datavalid.get_next_batch()
+                    vloss, vler = network.validate(vm, vl, vs, vll)
+                    logger.info('Valid: cost = %.4f' % vloss + ', ler = %.4f' % vler)
+        dataTrain.reset_epoch()
+    logger.info('Finished training!!!')
+    return network
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='Train speech recognizer on featurized mfcc files.')
+    ap.add_argument('config', help='Configuration file.')
+    args = ap.parse_args(argv)
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group('nccl')
+    config = Config(args.config, isTraining=True)
+    dataTrain = DataSet(config.train_input, config)
+    dataValid = None
+    if config.test_input:
+        config_test = Config(args.config, isTraining=True)
+        config_test.epochs = None
+        dataValid = DataSet(config_test.test_input, config_test)
+    train_model(dataTrain, dataValid, config)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,93 @@
+"""GPU, BASELINE.json's full sizes (B = 16, T = 500, F = 546, H = 500, C = 29): one direct comparison of
+the literal reference net against the fp64 oracle, plus size-independent properties."""
+import numpy as np
+import pytest
+
+from oracle import nasr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_for(spec, lr=1e-4):
+    from neuralasr_amd.engine import Engine
+    return Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
+                  learning_rate=lr)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def test_literal_net_full_size_matches_oracle():
+    spec = O.ModelSpec(546, 500, 1, True, 'stack_reshape', 29)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 16, 500, seed=1234, var_len=True)
+    params = O.init_params(spec, seed=1)
+    e = engine_for(spec)
+    e.set_params(O.flatten(params))
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    params32 = [p.astype(np.float32).astype(np.float64) for p in params]
+    loss_o, nll_o, grads_o, _ = O.network_loss_and_grads(spec, params32, feats, seq_len, labels, label_len)
+    assert loss == pytest.approx(loss_o, rel=1e-4)          # north-star: CTC loss within 1e-4 relative
+    np.testing.assert_allclose(nll, nll_o, rtol=1e-4)
+    for (name, off, r, c), g_o in zip(e.tensors(), grads_o):
+        g = grads[off:off + r * c].reshape(g_o.shape)
+        assert rel(g, g_o) < 2e-4, f'{name}: {rel(g, g_o):.2e}'
+    assert rel(grads, O.flatten(grads_o)) < 1e-4
+    e.close()
+
+
+@pytest.mark.parametrize('merge,layers', [('concat', 3), ('stack_reshape', 1)])
+def test_full_size_properties(merge, layers):
+    spec = O.ModelSpec(546, 500, layers, True, merge, 29)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 16, 500, seed=99, var_len=True)
+    e = engine_for(spec, lr=1e-3)
+    e.set_params(O.flatten(O.init_params(spec, seed=1)))
+    l1, nll1, g1 = e.loss_and_grads(feats, seq_len, labels, label_len)
+    # (a) finite, and the batch loss is the mean of the per-utterance losses
+    assert np.isfinite(g1).all() and np.isfinite(nll1).all()
+    assert l1 == pytest.approx(float(nll1.mean()), rel=1e-6)
+    # (b) every utterance's NLL is at least its label length times log(1/max prob) > 0 and below T*log(C)+slack
+    assert (nll1 > 0).all() and (nll1 < seq_len * np.log(29) * 1.5).all()
+    # (c) idempotence: the same inputs give the same loss and gradients again
+    l2, nll2, g2 = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert l1 == l2 and rel(g2, g1) < 1e-6
+    # (d) features past seq_len are never read: garbage there changes nothing
+    dirty = feats.copy()
+    for b in range(16):
+        dirty[b, seq_len[b]:] = 1e3
+    l3, _, g3 = e.loss_and_grads(dirty, seq_len, labels, label_len)
+    assert l3 == l1 and rel(g3, g1) < 1e-6
+    # (e) utterances are independent through the loss: permuting the batch permutes the NLLs
+    if merge == 'concat':
+        perm = np.random.RandomState(0).permutation(16)
+        _, nllp = e.loss(feats[perm], seq_len[perm], labels[perm], label_len[perm])
+        np.testing.assert_allclose(nllp, nll1[perm], rtol=1e-5)
+    # (f) directional derivative: loss(p - eps*g) ~ loss - eps*|g|^2
+    p0 = e.get_params()
+    gn = float(np.dot(g1.astype(np.float64), g1.astype(np.float64)))
+    eps = 1e-3 / np.sqrt(gn)
+    e.set_params(p0 - np.float32(eps) * g1)
+    l4, _ = e.loss(feats, seq_len, labels, label_len)
+    assert (l1 - l4) == pytest.approx(eps * gn, rel=0.05)
+    # (g) a few Adam steps reduce the loss
+    e.set_params(p0)
+    losses = [e.train_step(feats, seq_len, labels, label_len) for _ in range(4)]
+    assert losses[-1] < losses[0]
+    e.close()
+
+
+def test_time_sliced_towers_equal_one_tower_for_concat():
+    """n shards averaged == the global batch (A11) at full size, through get_grads/set_grads."""
+    spec = O.ModelSpec(546, 500, 1, True, 'concat', 29)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 32, 200, seed=5, var_len=True)
+    e = engine_for(spec)
+    e.set_params(O.flatten(O.init_params(spec, seed=1)))
+    lg, _, gg = e.loss_and_grads(feats, seq_len, labels, label_len)
+    acc, ls = 0, []
+    for sl in (slice(0, 16), slice(16, 32)):
+        l, _, g = e.loss_and_grads(feats[sl], seq_len[sl], labels[sl], label_len[sl])
+        acc = acc + g.astype(np.float64)
+        ls.append(l)
+    assert np.mean(ls) == pytest.approx(lg, rel=1e-6)
+    assert rel(acc / 2, gg) < 1e-5
+    e.close()

@@ -1,0 +1,131 @@
+"""GPU: the `Network` plugin surface end to end (config -> load_network -> train / validate / evaluate /
+decode / checkpoints) against the oracle's restatement of the reference's tower arithmetic."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from neuralasr_amd.config import Config
+from neuralasr_amd.dataset import DataSet
+from oracle import nasr_oracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+SAMPLES = os.path.join(HERE, 'golden', 'sample_set')
+
+
+def make_config(tmp_path, **over):
+    lines = open(os.path.join(SAMPLES, 'toy.config')).read().splitlines()
+    over = dict({'output': SAMPLES, 'model_dir': str(tmp_path / 'model')}, **over)
+    out = []
+    for ln in lines:
+        key = ln.split('=')[0]
+        out.append('%s=%s' % (key, over[key]) if key in over and '=' in ln else ln)
+    p = tmp_path / 'toy.config'
+    p.write_text('\n'.join(out) + '\n')
+    return str(p)
+
+
+def spec_of(net, cfg):
+    return O.ModelSpec(cfg.feature_size, net.num_hidden, net.num_layers, net.bidirectional, net.merge,
+                       cfg.symbols.counter)
+
+
+def test_load_network_by_reference_name_and_train_two_towers(tmp_path):
+    cfg = Config(make_config(tmp_path), True)
+    assert cfg.network == 'networks.bilstm_ctc_net.BiLstmCTCNet' and cfg.num_gpus == 2 and cfg.batch_size == 4
+    net = cfg.load_network(fortraining=True)
+    assert type(net).__name__ == 'BiLstmCTCNet' and net.engine.backend == 'hip-gfx950'
+    assert os.path.exists(os.path.join(cfg.model_dir, 'toy.config'))            # config + symbols copied
+    assert os.path.exists(os.path.join(cfg.model_dir, 'symbols'))
+    spec = spec_of(net, cfg)
+    params = [p.astype(np.float32).astype(np.float64) for p in O.unflatten(spec, net.engine.get_params())]
+    ds = DataSet(cfg.train_input, cfg)
+    mfccs, labels, seq_len, labels_len = ds.get_next_batch()
+    # oracle: two towers on contiguous halves, D3 map per tower, mean of tower means, TF Adam
+    loss_o, grads_o = O.data_parallel_loss_and_grads(spec, params, mfccs, [int(s) for s in seq_len], labels,
+                                                     labels_len, 2)
+    lers = []
+    for sl in O.shard_slices(4, 2):
+        lg, _ = O.network_forward(spec, params, mfccs[sl], [int(s) for s in seq_len[sl]])
+        hy = O.greedy_decode(lg, [int(s) for s in seq_len[sl]])
+        lers.append(O.label_error_rate(hy, labels[sl], labels_len[sl]))
+    newp, _, _ = O.adam_tf(params, grads_o, [0 * p for p in params], [0 * p for p in params], 1, cfg.learningrate)
+    loss, ler = net.train(mfccs, labels, seq_len, labels_len)
+    assert isinstance(loss, np.float32) and isinstance(ler, np.float32)
+    assert net.global_step == 1
+    assert float(loss) == pytest.approx(loss_o, rel=2e-5)
+    assert float(ler) == pytest.approx(np.mean(lers), abs=1e-6)
+    got = net.engine.get_params()
+    assert np.abs(got - O.flatten(newp)).max() < 0.02 * cfg.learningrate + 1e-6
+    v = net.validate(mfccs, labels, seq_len, labels_len)
+    assert isinstance(v, list) and len(v) == 2
+
+
+def test_checkpoint_cadence_resume_and_wipe(tmp_path):
+    cfg = Config(make_config(tmp_path, num_gpus=1, batch_size=4), True)
+    net = cfg.load_network(fortraining=True)
+    ds = DataSet(cfg.train_input, cfg)
+    b = ds.get_next_batch()
+    for _ in range(7):
+        net.train(*[b[0], b[1], b[2], b[3]])
+        net.save_checkpoint()
+    files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(cfg.model_dir, 'model-*.npz')))
+    assert files == ['model-%d.npz' % s for s in (3, 4, 5, 6, 7)]                 # Saver keeps 5
+    want = net.engine.get_params()
+    m, v, step = net.engine.get_adam_state()
+    assert step == 7
+    # resume: start_step > 0 restores the latest checkpoint (tfnetwork.py:142-147)
+    cfg2 = Config(make_config(tmp_path, num_gpus=1, batch_size=4, start_step=7), True)
+    net2 = cfg2.load_network(fortraining=True)
+    assert net2.global_step == 7
+    np.testing.assert_array_equal(net2.engine.get_params(), want)
+    m2, v2, step2 = net2.engine.get_adam_state()
+    assert step2 == 7
+    np.testing.assert_array_equal(m2, m)
+    l_a, _ = net.train(*b)
+    l_b, _ = net2.train(*b)
+    assert l_a == l_b                                                              # bitwise same continuation
+    # inference always restores (tfnetwork.py:46-51)
+    cfg3 = Config(make_config(tmp_path, num_gpus=1, batch_size=1), True)
+    net3 = cfg3.load_network(fortraining=False)
+    np.testing.assert_array_equal(net3.engine.get_params(), want)
+    # start_step == 0 wipes model_dir (tfnetwork.py:148-151)
+    cfg4 = Config(make_config(tmp_path, num_gpus=1, batch_size=4), True)
+    cfg4.load_network(fortraining=True)
+    assert glob.glob(os.path.join(cfg4.model_dir, 'model-*.npz')) == []
+
+
+def test_evaluate_and_decode_at_batch_one(tmp_path):
+    cfg = Config(make_config(tmp_path, num_gpus=1, batch_size=1), True)
+    net = cfg.load_network(fortraining=True)
+    spec = spec_of(net, cfg)
+    params = [p.astype(np.float64) for p in O.unflatten(spec, net.engine.get_params())]
+    ds = DataSet(cfg.test_input, cfg)
+    mfccs, labels, seq_len, labels_len = ds.get_next_batch()
+    ids, loss, ler = net.evaluate(mfccs, labels, seq_len, labels_len)
+    lo, nll, _, logits = O.network_loss_and_grads(spec, params, mfccs, [int(s) for s in seq_len], labels, labels_len)
+    hy = O.greedy_decode(logits, [int(s) for s in seq_len])
+    assert ids.dtype == np.int64 and ids.tolist() == hy[0]
+    assert float(loss) == pytest.approx(lo, rel=2e-5)
+    assert float(ler) == pytest.approx(O.label_error_rate(hy, labels, labels_len), abs=1e-6)
+    assert net.decode(mfccs, seq_len).tolist() == hy[0]
+    assert isinstance(cfg.symbols.convert_to_str(ids), str)
+
+
+def test_train_model_loop_end_to_end(tmp_path, caplog):
+    import logging
+    from neuralasr_amd import train as train_mod
+    cfg = Config(make_config(tmp_path, network='networks.lstm_ctc_net.SmallLstmCTCNet', epochs=3), True)
+    train = DataSet(cfg.train_input, cfg)
+    valid = DataSet(cfg.test_input, Config(make_config(tmp_path, network='networks.lstm_ctc_net.SmallLstmCTCNet'), True))
+    with caplog.at_level(logging.INFO, logger='NeuralASR'):
+        net = train_mod.train_model(train, valid, cfg)
+    assert net.global_step == 6
+    steps = [r.getMessage() for r in caplog.records if r.getMessage().startswith('Step: ')]
+    assert len(steps) == 3
+    costs = [float(m.split('cost = ')[1].split(',')[0]) for m in steps]
+    assert costs[-1] < costs[0]                                   # it learns the toy set
+    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(cfg.model_dir, 'model-*.npz'))) == \
+        ['model-2.npz', 'model-4.npz', 'model-6.npz']
