@@ -90,8 +90,11 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
   const float* lz = logz + b;
   auto emit = [&](int t, float (&e)[KS]) {               // t must be a valid frame (callers clamp)
     const float z = lz[(size_t)t * Bp];
+    float v[KS];
 #pragma unroll
-    for (int i = 0; i < KS; ++i) e[i] = act[i] ? lg[(size_t)t * rstride + ext[i]] - z : NEG;
+    for (int i = 0; i < KS; ++i) v[i] = lg[(size_t)t * rstride + ext[i]];   // unconditional: ext is always a class id
+#pragma unroll
+    for (int i = 0; i < KS; ++i) e[i] = act[i] ? v[i] - z : NEG;
   };
   float* ws = (w == 0 ? alpha : beta) + (size_t)b * Tws * KS * 64;
   double* off = (w == 0 ? aoff : boff) + (size_t)b * Tws;
