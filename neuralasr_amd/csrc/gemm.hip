@@ -35,6 +35,13 @@ __device__ __forceinline__ int phys_row(const int* map, int shift, int rows, int
   return (r >= 0 && r < rows) ? r : -1;
 }
 
+__device__ __forceinline__ float4 ld4(const float* __restrict__ p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// Every global load is unconditional (an invalid slot reads the matrix base and is zeroed by a select), so the
+// k-loop has no divergent branch and the staged tile lives in registers, not scratch.
 template <bool ACOL, bool BCOL>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
@@ -44,127 +51,134 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int kbeg = blockIdx.z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nk = (kend - kbeg) / BK;
+  const float* __restrict__ Ag = p.A;
+  const float* __restrict__ Bg = p.B;
 
-  // ---- per-thread global load slots: 2 float4 of A and 2 of B per k-tile
-  const float* aptr[2];
-  int a_i0[2], a_i1[2];   // LDS coordinates
-  const float* bptr[2];
-  int b_i0[2], b_i1[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int idx = tid + 256 * j;
-    if (!ACOL) {  // rows m, 4 consecutive k
-      const int mm = idx >> 2, kq = idx & 3;
-      a_i0[j] = mm; a_i1[j] = kq;
-      const int m = m0 + mm;
-      int pr = (m < p.M) ? phys_row(p.a_map, p.a_shift, p.a_rows, m) : -1;
-      aptr[j] = pr >= 0 ? p.A + (size_t)pr * p.lda + 4 * kq : nullptr;
-    } else {      // rows k, 4 consecutive m
-      const int kk = idx >> 5, mq = idx & 31;
-      a_i0[j] = kk; a_i1[j] = mq;
-      aptr[j] = (m0 + 4 * mq < p.M) ? p.A + m0 + 4 * mq : nullptr;
-    }
-    if (BCOL) {   // rows n, 4 consecutive k
-      const int nn = idx >> 2, kq = idx & 3;
-      b_i0[j] = nn; b_i1[j] = kq;
-      const int n = n0 + nn;
-      bptr[j] = (n < p.N) ? p.B + (size_t)n * p.ldb + 4 * kq : nullptr;
-    } else {      // rows k, 4 consecutive n
-      const int kk = idx >> 5, nq = idx & 31;
-      b_i0[j] = kk; b_i1[j] = nq;
-      bptr[j] = (n0 + 4 * nq < p.N) ? p.B + n0 + 4 * nq : nullptr;
-    }
+  // ---- two 16-byte load slots per operand per thread
+  // row-of-4-k slots (A when !ACOL, B when BCOL): r = idx>>2 (0..127), kq = idx&3
+  // row-of-4-m/n slots (A when ACOL, B when !BCOL): kk = idx>>5 (0..15), q = idx&31
+  const int r0 = tid >> 2, r1 = (tid + 256) >> 2, kq = tid & 3;
+  const int kk0 = tid >> 5, kk1 = (tid + 256) >> 5, q = tid & 31;
+  bool aok0, aok1, bok0, bok1;
+  size_t ao0 = 0, ao1 = 0, bo0 = 0, bo1 = 0;
+  if (!ACOL) {
+    const int pa0 = (m0 + r0 < p.M) ? phys_row(p.a_map, p.a_shift, p.a_rows, m0 + r0) : -1;
+    const int pa1 = (m0 + r1 < p.M) ? phys_row(p.a_map, p.a_shift, p.a_rows, m0 + r1) : -1;
+    aok0 = pa0 >= 0; aok1 = pa1 >= 0;
+    ao0 = aok0 ? (size_t)pa0 * p.lda + 4 * kq : 0;
+    ao1 = aok1 ? (size_t)pa1 * p.lda + 4 * kq : 0;
+  } else {
+    aok0 = aok1 = (m0 + 4 * q < p.M);
+    ao0 = ao1 = aok0 ? (size_t)(m0 + 4 * q) : 0;
+  }
+  if (BCOL) {
+    bok0 = n0 + r0 < p.N; bok1 = n0 + r1 < p.N;
+    bo0 = bok0 ? (size_t)(n0 + r0) * p.ldb + 4 * kq : 0;
+    bo1 = bok1 ? (size_t)(n0 + r1) * p.ldb + 4 * kq : 0;
+  } else {
+    bok0 = bok1 = (n0 + 4 * q < p.N);
+    bo0 = bo1 = bok0 ? (size_t)(n0 + 4 * q) : 0;
   }
 
-  float4 ra[2], rb[2];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (!ACOL) {
-        ra[j] = aptr[j] ? *reinterpret_cast<const float4*>(aptr[j] + k0) : z4;
-      } else {
-        int pr = phys_row(p.a_map, p.a_shift, p.a_rows, k0 + a_i0[j]);
-        ra[j] = (aptr[j] && pr >= 0) ? *reinterpret_cast<const float4*>(aptr[j] + (size_t)pr * p.lda) : z4;
-      }
-      if (BCOL) {
-        rb[j] = bptr[j] ? *reinterpret_cast<const float4*>(bptr[j] + k0) : z4;
-      } else {
-        rb[j] = bptr[j] ? *reinterpret_cast<const float4*>(bptr[j] + (size_t)(k0 + b_i0[j]) * p.ldb) : z4;
-      }
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (!ACOL) {
-        const int mm = a_i0[j], kq = a_i1[j];
-        As[buf][4 * kq + 0][mm] = ra[j].x; As[buf][4 * kq + 1][mm] = ra[j].y;
-        As[buf][4 * kq + 2][mm] = ra[j].z; As[buf][4 * kq + 3][mm] = ra[j].w;
-      } else {
-        *reinterpret_cast<float4*>(&As[buf][a_i0[j]][4 * a_i1[j]]) = ra[j];
-      }
-      if (BCOL) {
-        const int nn = b_i0[j], kq = b_i1[j];
-        Bs[buf][4 * kq + 0][nn] = rb[j].x; Bs[buf][4 * kq + 1][nn] = rb[j].y;
-        Bs[buf][4 * kq + 2][nn] = rb[j].z; Bs[buf][4 * kq + 3][nn] = rb[j].w;
-      } else {
-        *reinterpret_cast<float4*>(&Bs[buf][b_i0[j]][4 * b_i1[j]]) = rb[j];
-      }
-    }
-  };
+  float4 ra0, ra1, rb0, rb1;
+#define NASR_GLOAD(K0)                                                                              \
+  {                                                                                                 \
+    if (!ACOL) {                                                                                    \
+      ra0 = sel4(aok0, ld4(Ag + ao0 + (aok0 ? (K0) : 0)));                                          \
+      ra1 = sel4(aok1, ld4(Ag + ao1 + (aok1 ? (K0) : 0)));                                          \
+    } else {                                                                                        \
+      const int p0_ = phys_row(p.a_map, p.a_shift, p.a_rows, (K0) + kk0);                           \
+      const int p1_ = phys_row(p.a_map, p.a_shift, p.a_rows, (K0) + kk1);                           \
+      const bool o0_ = aok0 && p0_ >= 0, o1_ = aok1 && p1_ >= 0;                                    \
+      ra0 = sel4(o0_, ld4(Ag + (o0_ ? (size_t)p0_ * p.lda + ao0 : 0)));                             \
+      ra1 = sel4(o1_, ld4(Ag + (o1_ ? (size_t)p1_ * p.lda + ao1 : 0)));                             \
+    }                                                                                               \
+    if (BCOL) {                                                                                     \
+      rb0 = sel4(bok0, ld4(Bg + bo0 + (bok0 ? (K0) : 0)));                                          \
+      rb1 = sel4(bok1, ld4(Bg + bo1 + (bok1 ? (K0) : 0)));                                          \
+    } else {                                                                                        \
+      rb0 = sel4(bok0, ld4(Bg + (bok0 ? (size_t)((K0) + kk0) * p.ldb + bo0 : 0)));                  \
+      rb1 = sel4(bok1, ld4(Bg + (bok1 ? (size_t)((K0) + kk1) * p.ldb + bo1 : 0)));                  \
+    }                                                                                               \
+  }
+#define NASR_LSTORE(BUF)                                                                            \
+  {                                                                                                 \
+    if (!ACOL) {                                                                                    \
+      As[BUF][4 * kq + 0][r0] = ra0.x; As[BUF][4 * kq + 1][r0] = ra0.y;                             \
+      As[BUF][4 * kq + 2][r0] = ra0.z; As[BUF][4 * kq + 3][r0] = ra0.w;                             \
+      As[BUF][4 * kq + 0][r1] = ra1.x; As[BUF][4 * kq + 1][r1] = ra1.y;                             \
+      As[BUF][4 * kq + 2][r1] = ra1.z; As[BUF][4 * kq + 3][r1] = ra1.w;                             \
+    } else {                                                                                        \
+      *reinterpret_cast<float4*>(&As[BUF][kk0][4 * q]) = ra0;                                       \
+      *reinterpret_cast<float4*>(&As[BUF][kk1][4 * q]) = ra1;                                       \
+    }                                                                                               \
+    if (BCOL) {                                                                                     \
+      Bs[BUF][4 * kq + 0][r0] = rb0.x; Bs[BUF][4 * kq + 1][r0] = rb0.y;                             \
+      Bs[BUF][4 * kq + 2][r0] = rb0.z; Bs[BUF][4 * kq + 3][r0] = rb0.w;                             \
+      Bs[BUF][4 * kq + 0][r1] = rb1.x; Bs[BUF][4 * kq + 1][r1] = rb1.y;                             \
+      Bs[BUF][4 * kq + 2][r1] = rb1.z; Bs[BUF][4 * kq + 3][r1] = rb1.w;                             \
+    } else {                                                                                        \
+      *reinterpret_cast<float4*>(&Bs[BUF][kk0][4 * q]) = rb0;                                       \
+      *reinterpret_cast<float4*>(&Bs[BUF][kk1][4 * q]) = rb1;                                       \
+    }                                                                                               \
+  }
 
-  f32x16 acc[2][2];
+  f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
   const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
   const int li = lane & 31, lk = lane >> 5;
 
   if (nk > 0) {
-    gload(kbeg);
-    lstore(0);
+    NASR_GLOAD(kbeg);
+    NASR_LSTORE(0);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+    const bool more = kt + 1 < nk;
+    if (more) NASR_GLOAD(kbeg + (kt + 1) * BK);
+    // fragments of k-step ks+1 are read while the MFMAs of k-step ks issue
+    float a0 = As[buf][lk][wm + li], a1 = As[buf][lk][wm + 32 + li];
+    float b0 = Bs[buf][lk][wn + li], b1 = Bs[buf][lk][wn + 32 + li];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = 2 * ks + lk;
-      const float a0 = As[buf][k][wm + li], a1 = As[buf][k][wm + 32 + li];
-      const float b0 = Bs[buf][k][wn + li], b1 = Bs[buf][k][wn + 32 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (ks + 1 < BK / 2) {
+        const int k = 2 * (ks + 1) + lk;
+        na0 = As[buf][k][wm + li]; na1 = As[buf][k][wm + 32 + li];
+        nb0 = Bs[buf][k][wn + li]; nb1 = Bs[buf][k][wn + 32 + li];
+      }
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
+    if (more) NASR_LSTORE(buf ^ 1);
     __syncthreads();
   }
+#undef NASR_GLOAD
+#undef NASR_LSTORE
 
   // ---- epilogue: C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int t = 0; t < 4; ++t) {
+    const int mi = t >> 1, ni = t & 1;
+    const f32x16 acc = t == 0 ? acc00 : t == 1 ? acc01 : t == 2 ? acc10 : acc11;
+    const int col = n0 + wn + 32 * ni + li;
+    if (col >= p.N) continue;
+    const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + wn + 32 * ni + li;
-      if (col >= p.N) continue;
-      const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= p.M) continue;
-        if (p.split_k > 1) {
-          p.slabs[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[mi][ni][r];
-        } else {
-          const int pr = p.c_map ? p.c_map[row] : row;
-          if (pr >= 0) p.C[(size_t)pr * p.ldc + col] = acc[mi][ni][r] + bv;
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row >= p.M) continue;
+      if (p.split_k > 1) {
+        p.slabs[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[r];
+      } else {
+        const int pr = p.c_map ? p.c_map[row] : row;
+        if (pr >= 0) p.C[(size_t)pr * p.ldc + col] = acc[r] + bv;
       }
     }
   }
