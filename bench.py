@@ -111,7 +111,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ        # under torch.distributed.run even at N = 1
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
@@ -125,16 +126,16 @@ def main():
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1234 + rank, var_len=args.var_len)
     eng.upload_batch(feats, seq_len, labels, label_len)
     frames = eng.resident_frames()
-    gt = eng.grad_tensor() if world > 1 else None
+    gt = eng.grad_tensor() if use_dist else None
 
     def step():
         eng.compute_grads()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(gt, op=dist.ReduceOp.SUM)
         eng.apply_adam(1.0 / world)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -146,7 +147,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -208,7 +209,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -15,7 +15,10 @@ namespace nasr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+#ifndef NASR_GEMM_BK
+#define NASR_GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = NASR_GEMM_BK, LDT = 132;
 
 struct GemmParams {
   const float* A;
@@ -50,76 +53,73 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg) / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;      // a K tail (K % BK != 0, K % 4 == 0) is zero-filled
   const float* __restrict__ Ag = p.A;
   const float* __restrict__ Bg = p.B;
 
-  // ---- two 16-byte load slots per operand per thread
-  // row-of-4-k slots (A when !ACOL, B when BCOL): r = idx>>2 (0..127), kq = idx&3
-  // row-of-4-m/n slots (A when ACOL, B when !BCOL): kk = idx>>5 (0..15), q = idx&31
-  const int r0 = tid >> 2, r1 = (tid + 256) >> 2, kq = tid & 3;
-  const int kk0 = tid >> 5, kk1 = (tid + 256) >> 5, q = tid & 31;
-  bool aok0, aok1, bok0, bok1;
-  size_t ao0 = 0, ao1 = 0, bo0 = 0, bo1 = 0;
-  if (!ACOL) {
-    const int pa0 = (m0 + r0 < p.M) ? phys_row(p.a_map, p.a_shift, p.a_rows, m0 + r0) : -1;
-    const int pa1 = (m0 + r1 < p.M) ? phys_row(p.a_map, p.a_shift, p.a_rows, m0 + r1) : -1;
-    aok0 = pa0 >= 0; aok1 = pa1 >= 0;
-    ao0 = aok0 ? (size_t)pa0 * p.lda + 4 * kq : 0;
-    ao1 = aok1 ? (size_t)pa1 * p.lda + 4 * kq : 0;
-  } else {
-    aok0 = aok1 = (m0 + 4 * q < p.M);
-    ao0 = ao1 = aok0 ? (size_t)(m0 + 4 * q) : 0;
-  }
-  if (BCOL) {
-    bok0 = n0 + r0 < p.N; bok1 = n0 + r1 < p.N;
-    bo0 = bok0 ? (size_t)(n0 + r0) * p.ldb + 4 * kq : 0;
-    bo1 = bok1 ? (size_t)(n0 + r1) * p.ldb + 4 * kq : 0;
-  } else {
-    bok0 = bok1 = (n0 + 4 * q < p.N);
-    bo0 = bo1 = bok0 ? (size_t)(n0 + 4 * q) : 0;
+  // ---- NS 16-byte load slots per operand per thread (slot j covers idx = tid + 256*j)
+  //   "row" slots (A when !ACOL, B when BCOL): r = idx / KQ (0..127), kq = idx % KQ     (4 consecutive k)
+  //   "col" slots (A when ACOL, B when !BCOL): kk = idx >> 5 (0..BK-1), q = idx & 31    (4 consecutive m/n)
+  constexpr int NS = BK / 8, KQ = BK / 4;
+  bool aok[NS], bok[NS];
+  size_t ao[NS], bo[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int idx = tid + 256 * j;
+    const int r = idx / KQ, kq = idx % KQ, q = idx & 31;
+    if (!ACOL) {
+      const int pa = (m0 + r < p.M) ? phys_row(p.a_map, p.a_shift, p.a_rows, m0 + r) : -1;
+      aok[j] = pa >= 0;
+      ao[j] = aok[j] ? (size_t)pa * p.lda + 4 * kq : 0;
+    } else {
+      aok[j] = (m0 + 4 * q < p.M);
+      ao[j] = aok[j] ? (size_t)(m0 + 4 * q) : 0;
+    }
+    if (BCOL) {
+      bok[j] = n0 + r < p.N;
+      bo[j] = bok[j] ? (size_t)(n0 + r) * p.ldb + 4 * kq : 0;
+    } else {
+      bok[j] = (n0 + 4 * q < p.N);
+      bo[j] = bok[j] ? (size_t)(n0 + 4 * q) : 0;
+    }
   }
 
-  float4 ra0, ra1, rb0, rb1;
+  float4 ra[NS], rb[NS];
 #define NASR_GLOAD(K0)                                                                              \
-  {                                                                                                 \
+  _Pragma("unroll") for (int j = 0; j < NS; ++j) {                                                  \
+    const int kk_ = (tid + 256 * j) >> 5;                                                           \
+    const bool kr_ = (K0) + 4 * ((tid + 256 * j) % KQ) < kend, kc_ = (K0) + kk_ < kend;             \
     if (!ACOL) {                                                                                    \
-      ra0 = sel4(aok0, ld4(Ag + ao0 + (aok0 ? (K0) : 0)));                                          \
-      ra1 = sel4(aok1, ld4(Ag + ao1 + (aok1 ? (K0) : 0)));                                          \
+      const bool o_ = aok[j] && kr_;                                                                \
+      ra[j] = sel4(o_, ld4(Ag + (o_ ? ao[j] + (K0) : 0)));                                          \
     } else {                                                                                        \
-      const int p0_ = phys_row(p.a_map, p.a_shift, p.a_rows, (K0) + kk0);                           \
-      const int p1_ = phys_row(p.a_map, p.a_shift, p.a_rows, (K0) + kk1);                           \
-      const bool o0_ = aok0 && p0_ >= 0, o1_ = aok1 && p1_ >= 0;                                    \
-      ra0 = sel4(o0_, ld4(Ag + (o0_ ? (size_t)p0_ * p.lda + ao0 : 0)));                             \
-      ra1 = sel4(o1_, ld4(Ag + (o1_ ? (size_t)p1_ * p.lda + ao1 : 0)));                             \
+      const int pr_ = kc_ ? phys_row(p.a_map, p.a_shift, p.a_rows, (K0) + kk_) : -1;                \
+      const bool o_ = aok[j] && pr_ >= 0;                                                           \
+      ra[j] = sel4(o_, ld4(Ag + (o_ ? (size_t)pr_ * p.lda + ao[j] : 0)));                           \
     }                                                                                               \
     if (BCOL) {                                                                                     \
-      rb0 = sel4(bok0, ld4(Bg + bo0 + (bok0 ? (K0) : 0)));                                          \
-      rb1 = sel4(bok1, ld4(Bg + bo1 + (bok1 ? (K0) : 0)));                                          \
+      const bool o_ = bok[j] && kr_;                                                                \
+      rb[j] = sel4(o_, ld4(Bg + (o_ ? bo[j] + (K0) : 0)));                                          \
     } else {                                                                                        \
-      rb0 = sel4(bok0, ld4(Bg + (bok0 ? (size_t)((K0) + kk0) * p.ldb + bo0 : 0)));                  \
-      rb1 = sel4(bok1, ld4(Bg + (bok1 ? (size_t)((K0) + kk1) * p.ldb + bo1 : 0)));                  \
+      const bool o_ = bok[j] && kc_;                                                                \
+      rb[j] = sel4(o_, ld4(Bg + (o_ ? (size_t)((K0) + kk_) * p.ldb + bo[j] : 0)));                  \
     }                                                                                               \
   }
 #define NASR_LSTORE(BUF)                                                                            \
-  {                                                                                                 \
+  _Pragma("unroll") for (int j = 0; j < NS; ++j) {                                                  \
+    const int idx_ = tid + 256 * j;                                                                 \
+    const int r_ = idx_ / KQ, kq_ = idx_ % KQ, kk_ = idx_ >> 5, q_ = idx_ & 31;                     \
     if (!ACOL) {                                                                                    \
-      As[BUF][4 * kq + 0][r0] = ra0.x; As[BUF][4 * kq + 1][r0] = ra0.y;                             \
-      As[BUF][4 * kq + 2][r0] = ra0.z; As[BUF][4 * kq + 3][r0] = ra0.w;                             \
-      As[BUF][4 * kq + 0][r1] = ra1.x; As[BUF][4 * kq + 1][r1] = ra1.y;                             \
-      As[BUF][4 * kq + 2][r1] = ra1.z; As[BUF][4 * kq + 3][r1] = ra1.w;                             \
+      As[BUF][4 * kq_ + 0][r_] = ra[j].x; As[BUF][4 * kq_ + 1][r_] = ra[j].y;                       \
+      As[BUF][4 * kq_ + 2][r_] = ra[j].z; As[BUF][4 * kq_ + 3][r_] = ra[j].w;                       \
     } else {                                                                                        \
-      *reinterpret_cast<float4*>(&As[BUF][kk0][4 * q]) = ra0;                                       \
-      *reinterpret_cast<float4*>(&As[BUF][kk1][4 * q]) = ra1;                                       \
+      *reinterpret_cast<float4*>(&As[BUF][kk_][4 * q_]) = ra[j];                                    \
     }                                                                                               \
     if (BCOL) {                                                                                     \
-      Bs[BUF][4 * kq + 0][r0] = rb0.x; Bs[BUF][4 * kq + 1][r0] = rb0.y;                             \
-      Bs[BUF][4 * kq + 2][r0] = rb0.z; Bs[BUF][4 * kq + 3][r0] = rb0.w;                             \
-      Bs[BUF][4 * kq + 0][r1] = rb1.x; Bs[BUF][4 * kq + 1][r1] = rb1.y;                             \
-      Bs[BUF][4 * kq + 2][r1] = rb1.z; Bs[BUF][4 * kq + 3][r1] = rb1.w;                             \
+      Bs[BUF][4 * kq_ + 0][r_] = rb[j].x; Bs[BUF][4 * kq_ + 1][r_] = rb[j].y;                       \
+      Bs[BUF][4 * kq_ + 2][r_] = rb[j].z; Bs[BUF][4 * kq_ + 3][r_] = rb[j].w;                       \
     } else {                                                                                        \
-      *reinterpret_cast<float4*>(&Bs[BUF][kk0][4 * q]) = rb0;                                       \
-      *reinterpret_cast<float4*>(&Bs[BUF][kk1][4 * q]) = rb1;                                       \
+      *reinterpret_cast<float4*>(&Bs[BUF][kk_][4 * q_]) = rb[j];                                    \
     }                                                                                               \
   }
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
 int gemm_pick_split(int M, int N, int K) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int s = (384 + tiles - 1) / tiles;         // aim at >= ~1.5 blocks per CU
-  const int max_s = K / (BK * 8);            // keep >= 8 k-tiles per split
+  const int max_s = K / 128;                 // keep >= 128 k per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   if (tiles >= 192) s = 1;
@@ -218,7 +218,7 @@ void launch_gemm(const GemmDesc& g, hipStream_t st) {
   p.a_map = g.a_map; p.a_shift = g.a_shift; p.a_rows = g.a_rows; p.c_map = g.c_map; p.bias = g.bias;
   p.split_k = g.split_k < 1 ? 1 : g.split_k;
   p.slabs = g.slabs;
-  int kt = g.K / BK;
+  int kt = (g.K + BK - 1) / BK;
   int per = (kt + p.split_k - 1) / p.split_k;
   p.kchunk = per * BK;
   p.split_k = (kt + per - 1) / per;          // drop empty trailing splits

@@ -16,7 +16,7 @@ struct GemmDesc {
   const float* A;
   const float* B;
   float* C;
-  int M, N, K;          // K % 16 == 0, M % 4 == 0, N % 4 == 0
+  int M, N, K;          // K % 4 == 0, M % 4 == 0, N % 4 == 0
   int lda, ldb, ldc;    // element strides (multiples of 4)
   bool a_col;           // false: A(m,k) = A[row(m)*lda + k]      true: A(m,k) = A[row(k)*lda + m]
   bool b_col;           // false: B(k,n) = B[k*ldb + n]           true: B(k,n) = B[n*ldb + k]

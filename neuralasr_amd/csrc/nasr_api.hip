@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -71,6 +72,9 @@ struct nasr_ctx {
   int device = 0;
   hipStream_t st = nullptr;
   bool own_stream = false;
+  hipStream_t side = nullptr;          // low-priority stream: weight-gradient GEMMs of layer l under BPTT of layer l-1
+  bool overlap = true;
+  std::vector<hipEvent_t> ev_bptt, ev_wgrad;
   std::string err;
 
   // model dims
@@ -93,7 +97,7 @@ struct nasr_ctx {
   int64_t frames = 0;
   std::vector<int32_t> h_seq;
 
-  DevBuf feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
+  DevBuf feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, dgbuf2, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
       rowmap, slabs, csws, amax, ids, lens, stage;
   std::vector<DevBuf> gates, outb, cbuf;
 
@@ -305,6 +309,7 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->partial.ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
   ok &= h->dcstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
   ok &= h->dgbuf.ensure(R * D * N4 * 4, &grew);
+  if (h->L > 1 && h->overlap) ok &= h->dgbuf2.ensure(R * D * N4 * 4, &grew);
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
   const int KSa = KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations
@@ -419,6 +424,12 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
   return NASR_OK;
 }
 
+// dG of layer l: two buffers alternate so layer l's weight-gradient GEMMs (side stream) can still read theirs
+// while BPTT of layer l-1 writes the other
+float* dg_of(nasr_ctx* h, int l) {
+  return (h->L > 1 && h->overlap && (l & 1)) ? h->dgbuf2.as<float>() : h->dgbuf.as<float>();
+}
+
 // ---- the per-timestep loops, optionally replayed from a hipGraph ---------------------------
 int run_steps(nasr_ctx* h, int l, bool bwd) {
   const LstmDims dm{h->T, h->B, h->Bp, h->H, h->Hp, h->D};
@@ -440,7 +451,7 @@ int run_steps(nasr_ctx* h, int l, bool bwd) {
       for (int s = h->T - 1; s >= 0; --s, ++k)
         launch_lstm_bwd_step(dm, s, h->Ub + sU, h->partial.as<float>() + (k & 1) * ps,
                              h->partial.as<float>() + ((k + 1) & 1) * ps, h->gates[l].as<float>(),
-                             h->dgbuf.as<float>(), h->cbuf[l].as<float>(), h->dout.as<float>(),
+                             dg_of(h, l), h->cbuf[l].as<float>(), h->dout.as<float>(),
                              h->dcstate.as<float>() + (k & 1) * hs, h->dcstate.as<float>() + ((k + 1) & 1) * hs,
                              h->seq.as<int>(), h->st);
     }
@@ -581,7 +592,11 @@ int backward(nasr_ctx* h) {
     HIPCHK(h, hipGetLastError());
   }
   h->n_bwd_launch = 0;
+  const bool ov = h->overlap && h->L > 1 && h->side;
   for (int l = h->L - 1; l >= 0; --l) {
+    float* dG = dg_of(h, l);
+    // layer l+2 used this dG buffer: its weight-gradient GEMMs must have read it before BPTT overwrites it
+    if (ov && l + 2 < h->L) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_wgrad[l + 2], 0));
     {
       PhaseScope ps(h, PH_RECB);
       int rc = run_steps(h, l, true);
@@ -589,8 +604,21 @@ int backward(nasr_ctx* h) {
       h->n_bwd_launch += T;
     }
     PhaseScope ps(h, PH_WGRAD);
+    hipStream_t ws = h->st;
+    if (ov && l > 0) {   // the last layer processed (l = 0) has nothing left to hide under
+      HIPCHK(h, hipEventRecord(h->ev_bptt[l], h->st));
+      HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_bptt[l], 0));
+      ws = h->side;
+    }
+    if (l > 0) {  // critical path first: gradient wrt the layer input = the layer below's output
+      GemmDesc g{};
+      g.A = dG; g.B = h->P + h->off_wx[l]; g.C = h->dout.as<float>();
+      g.M = R; g.N = h->Ip[l]; g.K = D * N4;
+      g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp;
+      g.b_col = true; g.a_rows = R; g.split_k = 1;
+      launch_gemm(g, h->st);
+    }
     const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
-    float* dG = h->dgbuf.as<float>();
     {  // dWx = X^T dG
       GemmDesc g{};
       g.A = Xl; g.B = dG; g.C = h->G + h->off_wx[l];
@@ -600,9 +628,9 @@ int backward(nasr_ctx* h) {
       g.split_k = gemm_pick_split(g.M, g.N, g.K);
       g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
       if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm(g, h->st);
+      launch_gemm(g, ws);
     }
-    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), h->st);
+    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
     for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
       GemmDesc g{};
       g.A = h->outb[l].as<float>() + d * Hp;
@@ -614,18 +642,13 @@ int backward(nasr_ctx* h) {
       g.split_k = gemm_pick_split(g.M, g.N, g.K);
       g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
       if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm(g, h->st);
+      launch_gemm(g, ws);
     }
-    if (l > 0) {  // gradient wrt the layer input = the layer below's output
-      GemmDesc g{};
-      g.A = dG; g.B = h->P + h->off_wx[l]; g.C = h->dout.as<float>();
-      g.M = R; g.N = h->Ip[l]; g.K = D * N4;
-      g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp;
-      g.b_col = true; g.a_rows = R; g.split_k = 1;
-      launch_gemm(g, h->st);
-    }
+    if (ws != h->st) HIPCHK(h, hipEventRecord(h->ev_wgrad[l], ws));
     HIPCHK(h, hipGetLastError());
   }
+  if (ov)
+    for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_wgrad[l], 0));   // join
   h->have_grads = true;
   return NASR_OK;
 }
@@ -716,6 +739,23 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   h->gates.resize(h->L);
   h->outb.resize(h->L);
   h->cbuf.resize(h->L);
+  {
+    // Off by default: measured on MI355X (3x500, B 16, T 500) the weight-gradient GEMMs co-running with the
+    // latency-bound BPTT launches slow those by 30 % and the step gets 0.5 ms LONGER (20.4 vs 19.9 ms).
+    const char* e = getenv("NASR_OVERLAP");
+    h->overlap = (e && e[0] == '1');
+    if (h->overlap && h->L > 1) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) h->side = nullptr;
+      h->ev_bptt.resize(h->L);
+      h->ev_wgrad.resize(h->L);
+      for (int l = 0; l < h->L; ++l) {
+        (void)hipEventCreateWithFlags(&h->ev_bptt[l], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&h->ev_wgrad[l], hipEventDisableTiming);
+      }
+    }
+  }
   (void)hipEventCreate(&h->ev_total_a);
   (void)hipEventCreate(&h->ev_total_b);
   memset(&h->last_times, 0, sizeof(h->last_times));
@@ -728,10 +768,16 @@ int nasr_destroy(nasr_handle h) {
   if (!h) return NASR_OK;
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
+  if (h->side) {
+    (void)hipStreamSynchronize(h->side);
+    (void)hipStreamDestroy(h->side);
+  }
+  for (hipEvent_t e : h->ev_bptt) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_wgrad) (void)hipEventDestroy(e);
   drop_graphs(h);
   for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub})
     if (p) (void)hipFree(p);
-  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->logits, &h->logz,
+  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->dgbuf2, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
     b->release();
