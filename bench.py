@@ -73,7 +73,7 @@ def cpu_baseline(spec, B, seed):
         thr = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
     except Exception:
         thr = os.cpu_count() or 1
-    Tc = 24 if spec.num_layers > 1 else 60
+    Tc = 200 if spec.num_layers > 1 else 400     # ~10-20 s of CPU work on the GPU box's host
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, Tc, seed=seed)
     params = O.init_params(spec, seed=1)
     t0 = time.time()

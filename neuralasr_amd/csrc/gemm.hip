@@ -202,12 +202,12 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmParams p) {
 }
 
 int gemm_pick_split(int M, int N, int K) {
+  // 2 blocks per CU are resident (LDS 34 KB, 106 VGPRs): aim at >= 512 blocks, keep >= 128 k per split
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  int s = (384 + tiles - 1) / tiles;         // aim at >= ~1.5 blocks per CU
-  const int max_s = K / 128;                 // keep >= 128 k per split
+  int s = (512 + tiles - 1) / tiles;
+  const int max_s = K / 128;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
-  if (tiles >= 192) s = 1;
   return s;
 }
 
