@@ -8,10 +8,11 @@
 // [Bp,Hp]x[Hp,4Hp] recurrent product fused with the cell update.
 //
 // One launch = one timestep of BOTH directions (blockIdx.y).  Measured on MI355X (tools/stepbench.hip):
-// a dependent launch costs 1.55 us whatever its shape, and a CU pulls ~70 GB/s from its XCD's L2, so a
-// step is priced by BYTES PER CU, not by chip bandwidth.  Both kernels are therefore cut so that every
-// CU streams ~32 KB of recurrent weights (the matrices stay L2-resident across launches: block -> XCD
-// mapping is fixed) plus the smallest possible share of the step's state:
+// a dependent launch costs 1.55 us whatever its shape, and a CU pulls only ~35-70 GB/s from the Infinity
+// Cache / its XCD's L2 (PMC: every launch re-fetches the matrices through the fabric, the L2s do not keep
+// them across a kernel boundary), so a step is priced by BYTES PER CU, not by chip bandwidth.  Both kernels
+// are therefore cut so that every CU streams ~32 KB of recurrent weights plus the smallest possible share
+// of the step's state:
 //   forward : block = 4 hidden units x 4 gates (one 16-column MFMA tile), Hp/4 * D blocks (256 for
 //             2x512), its 4 waves split K = Hp and reduce through LDS; state = h (32 KB).
 //   backward: block = (64-unit output tile, 32-unit K slice); it rebuilds its slice of dG from the
