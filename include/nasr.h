@@ -143,6 +143,13 @@ int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the
 int nasr_set_step_decode(nasr_handle h, int enabled);
 int nasr_get_decoded(nasr_handle h, int32_t* ids_out /*[B,T']*/, int32_t* lens_out /*[B]*/);
 
+/* create_model (networks/tfnetwork.py:61-64): tf.nn.ctc_beam_search_decoder on host logits, time-major
+ * [T',B,C] (as nasr_forward returns them); TF defaults are beam_width 100, merge_repeated 1, top path only.
+ * ids_out [B,T'] (row b holds lens_out[b] ids), logp_out [B] = log-probability of the best beam (may be NULL).
+ * Host code (one thread per utterance), no GPU work. */
+int nasr_ctc_beam_search(const float* logits, const int32_t* seq_len, int B, int Tp, int C, int beam_width,
+                         int merge_repeated, int32_t* ids_out, int32_t* lens_out, float* logp_out);
+
 /* create_metric (networks/tfnetwork.py:66-70): mean over the batch of Levenshtein(hyp, truth)/len(truth)
  * (tf.edit_distance normalize=True, Appendix A.7).  Host code, no GPU work.  hyp_ids [B,hyp_stride],
  * labels [B,Lmax].  An empty truth gives inf for a non-empty hypothesis and 0 otherwise, as TF does. */

@@ -23,7 +23,7 @@ SYMBOLS = [
     'nasr_get_adam_state', 'nasr_set_learning_rate', 'nasr_train_step', 'nasr_forward', 'nasr_logit_frames',
     'nasr_loss', 'nasr_loss_and_grads', 'nasr_greedy_decode', 'nasr_upload_batch', 'nasr_compute_grads',
     'nasr_grad_device_ptr', 'nasr_grad_device_count', 'nasr_apply_adam', 'nasr_get_grads', 'nasr_set_grads',
-    'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_get_loss', 'nasr_resident_frames',
+    'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_ctc_beam_search', 'nasr_get_loss', 'nasr_resident_frames',
     'nasr_set_profiling', 'nasr_get_phase_times', 'nasr_set_graph_mode',
 ]
 
@@ -97,6 +97,7 @@ def load():
         'nasr_label_error_rate': (c_int, [ip, ip, c_int, ip, ip, c_int, c_int, fp]),
         'nasr_set_step_decode': (c_int, [H, c_int]),
         'nasr_get_decoded': (c_int, [H, ip, ip]),
+        'nasr_ctc_beam_search': (c_int, [fp, ip, c_int, c_int, c_int, c_int, c_int, ip, ip, fp]),
         'nasr_get_loss': (c_int, [H, fp]),
         'nasr_resident_frames': (c_int, [H, POINTER(c_int64)]),
         'nasr_set_profiling': (c_int, [H, c_int]),

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libnasr.so')
-SOURCES = ['gemm.hip', 'lstm.hip', 'ctc.hip', 'optim.hip', 'nasr_api.hip']
+SOURCES = ['gemm.hip', 'lstm.hip', 'ctc.hip', 'optim.hip', 'nasr_api.hip', 'beam.cpp']
 HEADERS = [os.path.join(CSRC, 'kernels.h'), os.path.join(HERE, '..', 'include', 'nasr.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -35,7 +35,7 @@ def build(force=False, verbose=False):
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(bdir, s.replace('.hip', '.o'))
+        obj = os.path.join(bdir, os.path.splitext(s)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
             jobs.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lpthread'])
     return LIB
 
 

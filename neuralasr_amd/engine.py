@@ -204,6 +204,21 @@ class Engine:
         self._ck(self.lib.nasr_get_decoded(self.h, _ip(ids), _ip(lens)))
         return [ids[b, :lens[b]].tolist() for b in range(B)]
 
+    def beam_search(self, logits_tm, seq_len, beam_width=100, merge_repeated=True):
+        """tf.nn.ctc_beam_search_decoder defaults (networks/tfnetwork.py:61-64) on host logits [T',B,C].
+        Returns (list of id lists, log-probabilities [B])."""
+        lg = _f32(logits_tm)
+        Tp, B, C = lg.shape
+        seq = _i32(np.asarray([int(x) for x in seq_len]))
+        ids = np.zeros((B, Tp), np.int32)
+        lens = np.zeros(B, np.int32)
+        logp = np.zeros(B, np.float32)
+        rc = self.lib.nasr_ctc_beam_search(_fp(lg), _ip(seq), B, Tp, C, int(beam_width), int(bool(merge_repeated)),
+                                           _ip(ids), _ip(lens), _fp(logp))
+        if rc != 0:
+            raise _lib.NasrError(rc, 'nasr_ctc_beam_search: bad arguments')
+        return [ids[b, :lens[b]].tolist() for b in range(B)], logp
+
     def get_loss(self):
         loss = c_float()
         self._ck(self.lib.nasr_get_loss(self.h, byref(loss)))

@@ -3,8 +3,10 @@ numpy-out train / validate / evaluate / decode, checkpoints, and data-parallel t
 arithmetic step in the HIP library behind include/nasr.h (no TensorFlow, no CPU fallback).
 
 Differences from the reference that a caller can observe, all deliberate and documented in DESIGN.md:
-  * the decoder behind `mean_ler`, evaluate() and decode() is the greedy CTC decoder the reference names in
-    the comment at tfnetwork.py:62-63, not beam search width 100 (a "next" row of SURVEY.md §8f);
+  * validate() / evaluate() / decode() use the reference's decoder (ctc_beam_search_decoder, width 100,
+    merge_repeated, host C++); the `mean_ler` that train() returns with every step uses the greedy decoder
+    the reference names in the comment at tfnetwork.py:62-63 (`train_ler_decoder = 'beam'` switches it, at
+    the price of a second forward pass and a CPU beam search per step);
   * num_gpus > 1 means one process per GPU (torch.distributed.run); inside a single process the towers are
     time-sliced on one GPU with the same split / averaging arithmetic;
   * checkpoints are `model-<step>.npz` (flat fp32 params + Adam m, v + step) with TF Saver's cadence and
@@ -45,6 +47,9 @@ class HipNetwork(Network):
     bidirectional = True
     merge = 'stack_reshape'
     keep_checkpoints = 5                     # tf.train.Saver() default max_to_keep
+    decoder = 'beam'                         # validate / evaluate / decode: tf.nn.ctc_beam_search_decoder defaults
+    train_ler_decoder = 'greedy'             # mean_ler of train(): greedy on the step's own logits
+    beam_width = 100
 
     def __init__(self, config, fortraining=False):
         Network.__init__(self)
@@ -130,9 +135,18 @@ class HipNetwork(Network):
             return n, [self.coll.rank]
         return n, list(range(n))
 
+    def _decode(self, mfccs, seq_len, which):
+        if which == 'beam':
+            logits = self.engine.forward(mfccs, seq_len)
+            return self.engine.beam_search(logits, seq_len, self.beam_width, merge_repeated=True)[0]
+        return self.engine.greedy_decode(mfccs, seq_len)
+
     def _loss_ler(self, mfccs, labels, seq_len, labels_len):
         loss, _ = self.engine.loss(mfccs, seq_len, labels, labels_len)
-        hyps = self.engine.get_decoded(len(seq_len), np.asarray(mfccs).shape[1])
+        if self.decoder == 'beam':
+            hyps = self._decode(mfccs, seq_len, 'beam')
+        else:
+            hyps = self.engine.get_decoded(len(seq_len), np.asarray(mfccs).shape[1])
         return loss, self.engine.label_error_rate(hyps, labels, labels_len), hyps
 
     def train(self, mfccs, labels, seq_len, labels_len):
@@ -144,7 +158,9 @@ class HipNetwork(Network):
             self.engine.upload_batch(f, s, l, ll)
             self.engine.compute_grads()
             losses.append(self.engine.get_loss())
-            lers.append(self.engine.label_error_rate(self.engine.get_decoded(len(s), f.shape[1]), l, ll))
+            hyps = (self._decode(f, s, 'beam') if self.train_ler_decoder == 'beam'
+                    else self.engine.get_decoded(len(s), f.shape[1]))
+            lers.append(self.engine.label_error_rate(hyps, l, ll))
             if len(mine) > 1:
                 g = self.engine.get_grads().astype(np.float64)
                 gsum = g if gsum is None else gsum + g
@@ -174,5 +190,5 @@ class HipNetwork(Network):
         return flat, np.float32(loss), np.float32(ler)
 
     def decode(self, mfccs, seq_len):
-        hyps = self.engine.greedy_decode(mfccs, seq_len)
+        hyps = self._decode(mfccs, seq_len, self.decoder)
         return np.asarray([i for h in hyps for i in h], dtype=np.int64)

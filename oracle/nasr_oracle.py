@@ -334,6 +334,115 @@ def greedy_decode(logits_tm, seq_len, blank=None):
     return out
 
 
+def ctc_beam_search(logits, beam_width=100, merge_repeated=True, blank=None):
+    """tf.nn.ctc_beam_search_decoder for one utterance (Appendix A.6; networks/tfnetwork.py:61-64 uses the
+    defaults beam_width=100, top_paths=1, merge_repeated=True).  logits [T,C] -> (ids, log_prob of the best
+    beam).  Restated from TF 1.x's documented per-frame procedure: every live prefix keeps
+    (p_blank, p_label, p_total); per frame first the probabilities of the live prefixes are advanced, then each
+    is grown by one label while the grown prefix can still enter the `beam_width` best.  Unpinned against TF;
+    pinned by exhaustive enumeration when the beam is wide enough (tests/test_beam.py)."""
+    logits = np.asarray(logits, np.float64)
+    T, C = logits.shape
+    blank = C - 1 if blank is None else blank
+    NEG = -np.inf
+
+    def lse2(a, b):
+        if a == NEG:
+            return b
+        if b == NEG:
+            return a
+        m = max(a, b)
+        return m + np.log(np.exp(a - m) + np.exp(b - m))
+
+    class Node:
+        __slots__ = ('parent', 'label', 'old', 'new', 'kids')
+
+        def __init__(self, parent, label):
+            self.parent, self.label, self.kids = parent, label, {}
+            self.old = [NEG, NEG, NEG]      # total, blank, label
+            self.new = [NEG, NEG, NEG]
+
+    root = Node(None, -1)
+    root.new = [0.0, 0.0, NEG]
+    leaves = [root]
+
+    def push(n):
+        if len(leaves) < beam_width:
+            leaves.append(n)
+            return
+        i = min(range(len(leaves)), key=lambda k: leaves[k].new[0])
+        if n.new[0] > leaves[i].new[0]:
+            leaves[i] = n
+
+    def candidate(p):
+        return p[0] > NEG and (len(leaves) < beam_width or p[0] > min(l.new[0] for l in leaves))
+
+    for t in range(T):
+        lp = log_softmax(logits[t])
+        branches = sorted(leaves, key=lambda n: -n.new[0])
+        leaves = []
+        for n in branches:
+            n.old = list(n.new)
+        for n in branches:
+            if n.parent is not None:
+                if n.parent.new[0] != NEG:
+                    prev = n.parent.old[1] if n.label == n.parent.label else n.parent.old[0]
+                    n.new[2] = lse2(n.new[2], prev)
+                n.new[2] += lp[n.label]
+            n.new[1] = n.old[0] + lp[blank]
+            n.new[0] = lse2(n.new[1], n.new[2])
+            push(n)
+        for n in branches:
+            if not candidate(n.old):
+                continue
+            for lab in range(C):
+                if lab == blank:
+                    continue
+                c = n.kids.get(lab)
+                if c is None:
+                    c = n.kids[lab] = Node(n, lab)
+                if c.new[0] != NEG:
+                    continue
+                prev = n.old[1] if lab == n.label else n.old[0]
+                c.new = [lp[lab] + prev, NEG, lp[lab] + prev]
+                if candidate(c.new):
+                    if len(leaves) == beam_width:
+                        i = min(range(len(leaves)), key=lambda k: leaves[k].new[0])
+                        leaves[i].new = [NEG, NEG, NEG]
+                    push(c)
+                else:
+                    c.old = [NEG, NEG, NEG]
+                    c.new = [NEG, NEG, NEG]
+    best = max(leaves, key=lambda n: n.new[0])
+    seq, prev, n = [], -1, best
+    while n.parent is not None:
+        if not merge_repeated or n.label != prev:
+            seq.append(n.label)
+        prev = n.label
+        n = n.parent
+    return seq[::-1], best.new[0]
+
+
+def ctc_best_labelling_brute_force(logits, blank):
+    """argmax over label sequences of the summed alignment probability (exponential; tiny cases only)."""
+    logits = np.asarray(logits, np.float64)
+    T, C = logits.shape
+    p = np.exp(log_softmax(logits))
+    tot = {}
+    for path in itertools.product(range(C), repeat=T):
+        col, prev = [], None
+        for k in path:
+            if k != prev and k != blank:
+                col.append(k)
+            prev = k
+        pr = 1.0
+        for t, k in enumerate(path):
+            pr *= p[t, k]
+        tot[tuple(col)] = tot.get(tuple(col), 0.0) + pr
+    best = max(tot, key=tot.get)
+    return list(best), float(np.log(tot[best])), tot
+
+
 def edit_distance(hyp, truth):
     """Levenshtein distance (tf.edit_distance core, Appendix A.7)."""
     n, m = len(hyp), len(truth)

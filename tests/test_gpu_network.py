@@ -104,11 +104,20 @@ def test_evaluate_and_decode_at_batch_one(tmp_path):
     params = [p.astype(np.float64) for p in O.unflatten(spec, net.engine.get_params())]
     ds = DataSet(cfg.test_input, cfg)
     mfccs, labels, seq_len, labels_len = ds.get_next_batch()
+    sl = [int(s) for s in seq_len]
+    lo, nll, _, logits = O.network_loss_and_grads(spec, params, mfccs, sl, labels, labels_len)
+    # default decoder = the reference's: beam width 100, merge_repeated (tfnetwork.py:61-64)
     ids, loss, ler = net.evaluate(mfccs, labels, seq_len, labels_len)
-    lo, nll, _, logits = O.network_loss_and_grads(spec, params, mfccs, [int(s) for s in seq_len], labels, labels_len)
-    hy = O.greedy_decode(logits, [int(s) for s in seq_len])
-    assert ids.dtype == np.int64 and ids.tolist() == hy[0]
+    hy_beam = [O.ctc_beam_search(logits[:sl[0], 0], 100, True)[0]]
+    assert ids.dtype == np.int64 and ids.tolist() == hy_beam[0]
     assert float(loss) == pytest.approx(lo, rel=2e-5)
+    assert float(ler) == pytest.approx(O.label_error_rate(hy_beam, labels, labels_len), abs=1e-6)
+    assert net.decode(mfccs, seq_len).tolist() == hy_beam[0]
+    # greedy variant (the decoder named in the comment at tfnetwork.py:62-63)
+    net.decoder = 'greedy'
+    hy = O.greedy_decode(logits, sl)
+    ids, loss, ler = net.evaluate(mfccs, labels, seq_len, labels_len)
+    assert ids.tolist() == hy[0]
     assert float(ler) == pytest.approx(O.label_error_rate(hy, labels, labels_len), abs=1e-6)
     assert net.decode(mfccs, seq_len).tolist() == hy[0]
     assert isinstance(cfg.symbols.convert_to_str(ids), str)
