@@ -42,10 +42,14 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_product_package_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/ (comments may cite it)."""
     pkg = os.path.join(ROOT, 'neuralasr_amd')
+    py_use = re.compile(r'^\s*(from\s+oracle|import\s+oracle|from\s+\.+oracle)|oracle\.nasr_oracle|nasr_oracle\s*\(', re.M)
+    c_use = re.compile(r'#\s*include\s*[<"][^>"]*oracle', re.M)
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith(('.py', '.hip', '.h', '.cpp')):
-                src = open(os.path.join(dirpath, f)).read()
-                assert 'oracle' not in src.replace('oracle/', '').lower() or f == 'build.py', \
-                    f'{f} mentions the oracle: the product path must not depend on test infrastructure'
+            src_path = os.path.join(dirpath, f)
+            if f.endswith('.py'):
+                assert not py_use.search(open(src_path).read()), f'{f} imports the oracle'
+            elif f.endswith(('.hip', '.h', '.cpp')):
+                assert not c_use.search(open(src_path).read()), f'{f} includes oracle code'
