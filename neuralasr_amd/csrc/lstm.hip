@@ -306,23 +306,23 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
       const int tb = val[e] ? (d ? (lenv[e] - 1 - s) : s) : 0;
       const int r = tb * Bp + b;
       rr[e] = r;
-      a[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      cc[e] = cpv[e] = dh[e] = dci[e] = 0.f;
-      if (val[e]) {
-        a[e] = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);  // si,tj,sf,so
-        cc[e] = cbuf[(size_t)r * DH + d * Hp + j];
-        if (s > 0) cpv[e] = cbuf[(size_t)(d ? r + Bp : r - Bp) * DH + d * Hp + j];
-        dh[e] = dout[(size_t)r * DH + d * Hp + j];
-        dci[e] = dcin[((size_t)d * Bp + b) * Hp + j];
-        const float* pp = pbase + (size_t)b * Hp + j;
-        if (KSP > 0) {
+      // unconditional loads (a masked cell reads frame 0 of its row and is zeroed below): no divergent
+      // branch, so both cells' loads are in flight together
+      const int rp = s > 0 ? (d ? r + Bp : r - Bp) : r;
+      a[e] = *reinterpret_cast<const float4*>(gates + (size_t)r * DN + d * N4 + 4 * j);  // si,tj,sf,so
+      cc[e] = cbuf[(size_t)r * DH + d * Hp + j];
+      cpv[e] = cbuf[(size_t)(val[e] ? rp : r) * DH + d * Hp + j];
+      if (s == 0) cpv[e] = 0.f;
+      dh[e] = dout[(size_t)r * DH + d * Hp + j];
+      dci[e] = dcin[((size_t)d * Bp + b) * Hp + j];
+      const float* pp = pbase + (size_t)b * Hp + j;
+      if (KSP > 0) {
 #pragma unroll
-          for (int k = 0; k < KV; ++k) pv[e][k] = pp[(size_t)k * Bp * Hp];
-        } else {
-          float acc0 = 0.f;
-          for (int k = 0; k < KSPLIT; ++k) acc0 += pp[(size_t)k * Bp * Hp];
-          pv[e][0] = acc0;
-        }
+        for (int k = 0; k < KV; ++k) pv[e][k] = pp[(size_t)k * Bp * Hp];
+      } else {
+        float acc0 = 0.f;
+        for (int k = 0; k < KSPLIT; ++k) acc0 += pp[(size_t)k * Bp * Hp];
+        pv[e][0] = acc0;
       }
     }
 #pragma unroll
@@ -344,11 +344,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
         dg.z = dct * cpv[e] * a[e].z * (1.f - a[e].z);
         dg.w = dhs * tc * a[e].w * (1.f - a[e].w);
         dcn = dct * a[e].z;
-        if (jt == 0) *reinterpret_cast<float4*>(dgbuf + (size_t)rr[e] * DN + d * N4 + 4 * j) = dg;
-      } else if (jt == 0 && s < T) {
-        *reinterpret_cast<float4*>(dgbuf + ((size_t)s * Bp + b) * DN + d * N4 + 4 * j) = dg;
       }
-      if (jt == 0) dcout[((size_t)d * Bp + b) * Hp + j] = dcn;
+      if (jt == 0) {   // the frame of a masked step is frame s itself (past seq_len in both directions): dG = 0 there
+        const size_t row = val[e] ? (size_t)rr[e] : (size_t)s * Bp + b;
+        *reinterpret_cast<float4*>(dgbuf + row * DN + d * N4 + 4 * j) = dg;
+        dcout[((size_t)d * Bp + b) * Hp + j] = dcn;
+      }
       As[mt][0 * 32 + ju][b16] = dg.x;
       As[mt][1 * 32 + ju][b16] = dg.y;
       As[mt][2 * 32 + ju][b16] = dg.z;
