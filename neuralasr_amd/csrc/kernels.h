@@ -31,6 +31,21 @@ struct GemmDesc {
 void launch_gemm(const GemmDesc& g, hipStream_t st);
 int gemm_pick_split(int M, int N, int K);
 
+// ---- fp32-accurate NT GEMM on the bf16 matrix cores (gemm_bf16.hip): C[M,N] = A[M,K] * B[N,K]^T (+bias) ----
+struct GemmNTDesc {
+  const float* A;       // [M][lda], K contiguous
+  const float* B;       // [N][ldb], K contiguous
+  float* C;             // [M][ldc]
+  int M, N, K;          // all multiples of 4
+  int lda, ldb, ldc;
+  int a_kshift;         // A read at k + a_kshift, zero outside [0,K)
+  const float* bias;    // per-n or NULL
+  int split_k;
+  float* slabs;         // split_k*M*N floats when split_k > 1
+};
+void launch_gemm_nt(const GemmNTDesc& g, hipStream_t st);
+void launch_transpose(const float* in, float* out, int R, int C, int ld_in, int ld_out, hipStream_t st);
+
 // ---- LSTM recurrence (lstm.hip) ----
 struct LstmDims {
   int T, B, Bp, H, Hp, D;   // D directions

@@ -25,6 +25,9 @@
 // C/D col = l&15, row = 4*(l>>4) + reg.
 #include "kernels.h"
 
+#ifndef NASR_NT
+#define NASR_NT 0    // 1: non-temporal loads for the recurrent weights (tools/stepbench.hip experiment)
+#endif
 #ifndef NASR_ABL
 #define NASR_ABL 0   // tools/stepbench.hip ablation mask: 1 no U loads, 2 no h loads, 4 no MFMA, 8 no cell I/O
 #endif
@@ -33,6 +36,15 @@ namespace nasr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ float4 ldw(const float4* p) {
+#if NASR_NT
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m)
       av[m][x] = (NASR_ABL & 2) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ha[((size_t)m * (Hp >> 4) + x) * 64];
-    bu[x] = (NASR_ABL & 1) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ub[(size_t)x * 64];
+    bu[x] = (NASR_ABL & 1) ? make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f) : ldw(ub + (size_t)x * 64);
   }
 
   // ---- cell threads: issue the loads the cell update needs
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
       for (int x = 0; x < CH; ++x) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) av[m][x] = ha[((size_t)m * (Hp >> 4) + qc + x) * 64];
-        bu[x] = ub[(size_t)(qc + x) * 64];
+        bu[x] = ldw(ub + (size_t)(qc + x) * 64);
       }
     }
 #pragma unroll
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int q2 = 0; q2 < 2; ++q2) bu[nt][q2] = ub[(size_t)(nt * 2 + q2) * 64];
+    for (int q2 = 0; q2 < 2; ++q2) bu[nt][q2] = ldw(ub + (size_t)(nt * 2 + q2) * 64);
 
   // ---- P stage: 2*MT cells per thread, processed in pairs: every load of a pair is issued before any
   // of its arithmetic so the two latency chains overlap.

@@ -1,6 +1,8 @@
 // gemmbench.hip — times the GEMM shapes of the training step (B 16, T 500, H 500, F 546).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DNASR_GEMM_BK=..] tools/gemmbench.hip -o tools/sb_gemm
 #include "../neuralasr_amd/csrc/gemm.hip"
+#include "../neuralasr_amd/csrc/gemm_bf16.hip"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -41,5 +43,36 @@ int main() {
     double fl = 2.0 * c.g.M * c.g.N * c.g.K;
     printf("%s split %d : %.3f ms  %.1f TF\n", c.name, c.g.split_k, best, fl / best / 1e9);
   }
+  // ---- bf16x6 NT kernel: numerics vs the fp32 kernel (same data, NT form) and speed
+  struct NT { const char* name; int M, N, K, split; const float* A; size_t a_elems; const float* B; size_t b_elems; };
+  const size_t nX = (size_t)R * 1024, nG = (size_t)R * 4096, nW = (size_t)1024 * 4096;
+  std::vector<NT> nts = {{"xproj  NT 8000x4096x576 ", R, 4096, 576, 1, X, nX, W, nW}, {"xproj  NT 8000x4096x1024", R, 4096, 1024, 1, X, nX, W, nW},
+                         {"dX     NT 8000x1024x4096", R, 1024, 4096, 1, G, nG, W, nW}, {"dWx    NT 576x4096x8000 ", 576, 4096, R, 4, X, nX, G, nG},
+                         {"dWx    NT 1024x4096x8000", 1024, 4096, R, 2, X, nX, G, nG}, {"dU     NT 512x2048x8000 ", 512, 2048, R, 8, X, nX, G, nG}};
+  float* O2 = dev_rand((size_t)R * 4096);
+  for (auto& c : nts) {
+    // operands: A [M][K] = X viewed with lda = K, B [N][K] = G viewed with ldb = K (both buffers are large enough)
+    if ((size_t)c.M * c.K > c.a_elems || (size_t)c.N * c.K > c.b_elems || (size_t)c.M * c.N > nG ||
+        (size_t)c.split * c.M * c.N > (size_t)8 * 1024 * 4096) { printf("%s: operand does not fit its buffer, skipped\n", c.name); continue; }
+    GemmNTDesc g{}; g.A = c.A; g.B = c.B; g.C = O; g.M = c.M; g.N = c.N; g.K = c.K; g.lda = c.K; g.ldb = c.K; g.ldc = c.N;
+    g.split_k = c.split; g.slabs = slabs;
+    GemmDesc f{}; f.A = c.A; f.B = c.B; f.C = O2; f.M = c.M; f.N = c.N; f.K = c.K; f.lda = c.K; f.ldb = c.K; f.ldc = c.N;
+    f.b_col = true; f.a_rows = c.M; f.split_k = 1;
+    launch_gemm_nt(g, st); launch_gemm(f, st); CK(hipStreamSynchronize(st));
+    std::vector<float> h1((size_t)c.M * c.N), h2((size_t)c.M * c.N);
+    CK(hipMemcpy(h1.data(), O, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), O2, h2.size() * 4, hipMemcpyDeviceToHost));
+    double num = 0, den = 0, mx = 0;
+    for (size_t i = 0; i < h1.size(); ++i) { double d = (double)h1[i] - h2[i]; num += d * d; den += (double)h2[i] * h2[i]; if (fabs(d) > mx) mx = fabs(d); }
+    float best = 1e9f;
+    for (int i = 0; i < 10; ++i) {
+      CK(hipEventRecord(a, st)); launch_gemm_nt(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+    }
+    printf("bf16x6 %s split %d : %.3f ms  %.1f TF-equiv   rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, c.split, best,
+           2.0 * c.M * c.N * c.K / best / 1e9, sqrt(num / den), mx);
+  }
+  // transpose
+  { float best = 1e9f; for (int i = 0; i < 5; ++i) { CK(hipEventRecord(a, st)); launch_transpose(G, O, R, 4096, 4096, R, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; }
+    printf("transpose 8000x4096: %.3f ms\n", best); }
   return 0;
 }
