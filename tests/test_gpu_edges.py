@@ -1,0 +1,126 @@
+"""GPU edge cases the reference's domain has: empty labels, single frames, the largest batch, long label
+sequences (several lattice states per lane), a large symbol table (label_context >= 1 creates n-gram
+symbols, preprocess_mfcc.py:22-26), hidden sizes that take every kernel template path."""
+import numpy as np
+import pytest
+
+from oracle import nasr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_for(spec):
+    from neuralasr_amd.engine import Engine
+    return Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
+                  learning_rate=1e-3)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def check(spec, feats, seq_len, labels, label_len, seed=3, gtol=1e-4):
+    rs = np.random.RandomState(seed)
+    params = [p + 0.05 * rs.randn(*p.shape) for p in O.init_params(spec, seed=seed)]
+    params = [p.astype(np.float32).astype(np.float64) for p in params]
+    e = engine_for(spec)
+    e.set_params(O.flatten(params))
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    lo, nllo, go, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+    np.testing.assert_allclose(e.forward(feats, seq_len), logits_o, atol=2e-4)
+    assert loss == pytest.approx(lo, rel=3e-5)
+    np.testing.assert_allclose(nll, nllo, rtol=3e-5, atol=1e-5)
+    assert rel(grads, O.flatten(go)) < gtol
+    e.close()
+
+
+def test_empty_labels_and_single_frames():
+    spec = O.ModelSpec(6, 16, 1, True, 'concat', 5)
+    rs = np.random.RandomState(0)
+    feats = rs.randn(5, 7, 6).astype(np.float32)
+    seq_len = np.array([7, 1, 3, 1, 7], np.int32)
+    for b in range(5):
+        feats[b, seq_len[b]:] = 0
+    labels = np.array([[1, 2, 3], [0, 0, 0], [0, 0, 0], [2, 0, 0], [1, 1, 2]], np.int32)
+    label_len = np.array([3, 0, 0, 1, 3], np.int32)          # empty labels: nll = -sum log p(blank)
+    check(spec, feats, seq_len, labels, label_len)
+
+
+def test_all_labels_empty():
+    spec = O.ModelSpec(6, 16, 1, False, 'none', 4)
+    feats, seq_len, _, _ = O.synth_batch(spec, 3, 5, seed=1)
+    check(spec, feats, seq_len, np.zeros((3, 1), np.int32), np.zeros(3, np.int32))
+
+
+def test_T_equals_one():
+    spec = O.ModelSpec(4, 16, 1, True, 'stack_reshape', 4)
+    rs = np.random.RandomState(2)
+    feats = rs.randn(3, 1, 4).astype(np.float32)
+    check(spec, feats, np.array([1, 1, 1], np.int32), np.array([[1], [0], [2]], np.int32), np.array([1, 0, 1], np.int32))
+
+
+@pytest.mark.parametrize("B", [17, 48, 64])
+def test_batch_up_to_four_m_tiles(B):
+    spec = O.ModelSpec(8, 24, 1, True, 'stack_reshape' if B == 64 else 'concat', 6)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, 9, seed=B, var_len=True, Lmin=1, Lmax=3)
+    check(spec, feats, seq_len, labels, label_len)
+
+
+def test_batch_above_64_is_rejected():
+    from neuralasr_amd import _lib
+    spec = O.ModelSpec(8, 16, 1, True, 'concat', 6)
+    e = engine_for(spec)
+    feats = np.zeros((65, 4, 8), np.float32)
+    with pytest.raises(_lib.NasrError, match=r'\[1,64\]'):
+        e.forward(feats, [4] * 65)
+    e.close()
+
+
+@pytest.mark.parametrize("Lmax,T", [(40, 90), (100, 230), (200, 420)])
+def test_long_labels_many_states_per_lane(Lmax, T):
+    spec = O.ModelSpec(5, 16, 1, True, 'concat', 7)
+    rs = np.random.RandomState(Lmax)
+    B = 3
+    seq_len = np.array([T, T - 7, T], np.int32)
+    feats = rs.randn(B, T, 5).astype(np.float32)
+    feats[1, T - 7:] = 0
+    label_len = np.array([Lmax, Lmax // 2, 1], np.int32)
+    labels = np.zeros((B, Lmax), np.int32)
+    for b in range(B):
+        # alternate labels so adjacent repeats stay rare and the label fits T
+        labels[b, :label_len[b]] = (np.arange(label_len[b]) % 5) + rs.randint(0, 2, label_len[b]) * 0
+    check(spec, feats, seq_len, labels, label_len, gtol=2e-4)
+
+
+def test_label_too_long_for_lattice_kernel_is_an_error():
+    from neuralasr_amd import _lib
+    spec = O.ModelSpec(5, 16, 1, True, 'concat', 7)
+    e = engine_for(spec)
+    T, L = 1200, 520
+    feats = np.zeros((1, T, 5), np.float32)
+    labels = (np.arange(L) % 5).reshape(1, L).astype(np.int32)
+    with pytest.raises(_lib.NasrError, match='label length'):
+        e.loss(feats, [T], labels, [L])
+    e.close()
+
+
+def test_large_symbol_table():
+    """label_context = 1 makes tri-gram symbols: C in the thousands."""
+    spec = O.ModelSpec(7, 16, 1, True, 'concat', 3000)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 3, 12, seed=9, var_len=True, Lmin=2, Lmax=5)
+    check(spec, feats, seq_len, labels, label_len)
+    e = engine_for(spec)
+    rs = np.random.RandomState(1)
+    params = [p + 0.3 * rs.randn(*p.shape) for p in O.init_params(spec, seed=2)]
+    e.set_params(O.flatten(params))
+    lg = e.forward(feats, seq_len)
+    assert e.greedy_decode(feats, seq_len) == O.greedy_decode(lg.astype(np.float64), seq_len)
+    e.close()
+
+
+@pytest.mark.parametrize("H,layers,bi", [(128, 1, True), (200, 2, True), (1024, 1, True), (1100, 1, False)])
+def test_hidden_sizes_cover_every_template_path(H, layers, bi):
+    """Hp = 128 / 256 / 1024 / 1152: NQ = 2, 4, 16 and the generic (runtime) forms; KSPLIT 4, 8, 32, 36."""
+    spec = O.ModelSpec(9, H, layers, bi, 'concat' if bi else 'none', 6)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 4, 6, seed=H, var_len=True, Lmin=1, Lmax=2)
+    check(spec, feats, seq_len, labels, label_len)
