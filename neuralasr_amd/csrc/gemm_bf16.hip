@@ -14,10 +14,11 @@
 // prefetch of the next k-tile while the current one is multiplied.
 //
 // STATUS (round 1): validated against the f32-MFMA kernel (relative L2 5e-7 .. 2e-6 on the step's shapes,
-// tools/gemmbench.hip) and measured at 123-146 TF-equivalent vs 96-105 TF for gemm.hip, i.e. only 1.3x: the
-// on-the-fly split costs ~250 VALU ops and 48 KB of ds_write_b64 per k-tile, which do not hide under the MFMAs
-// with one barrier pair per tile.  It is therefore NOT yet wired into the training step (the step would also
-// need transposed copies of X / out / dG for the weight-gradient GEMMs); it is kept as the next lever.
+// tools/gemmbench.hip) and measured at 123-146 TF-equivalent vs 96-105 TF for gemm.hip (1.3-1.4x).  It is the
+// default for the input-to-hidden, input-gradient and weight-gradient GEMMs (NASR_GEMM=f32 selects gemm.hip):
+// 3x500 step 19.0 -> 17.1 ms.  The projection GEMMs keep gemm.hip (row gather/scatter maps).  The on-the-fly
+// split (~180 VALU ops + 48 KB of ds_write_b64 per k-tile per block) is what keeps it from the 2.7x the MFMA
+// count alone would give.
 #include "kernels.h"
 
 namespace nasr {

@@ -28,6 +28,9 @@
 #ifndef NASR_NT
 #define NASR_NT 0    // 1: non-temporal loads for the recurrent weights (tools/stepbench.hip experiment)
 #endif
+#ifndef NASR_NTST
+#define NASR_NTST 0  // 1: non-temporal stores for the state handed to the next launch (experiment)
+#endif
 #ifndef NASR_ABL
 #define NASR_ABL 0   // tools/stepbench.hip ablation mask: 1 no U loads, 2 no h loads, 4 no MFMA, 8 no cell I/O
 #endif
@@ -43,6 +46,13 @@ __device__ __forceinline__ float4 ldw(const float4* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 #else
   return *p;
+#endif
+}
+__device__ __forceinline__ void st_state(float* p, float v) {
+#if NASR_NTST
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
 #endif
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
         cbuf[(size_t)r * DH + d * Hp + j] = c;
         out[(size_t)r * DH + d * Hp + j] = h;
       }
-      if (!(NASR_ABL & 32) || h == 123.456f) *hdst = h;
+      if (!(NASR_ABL & 32) || h == 123.456f) st_state(hdst, h);
     } else {
       // frame s of row b is past seq_len for both directions: zero output (A.2); state is dead
       if (s < T) out[((size_t)s * Bp + b) * DH + d * Hp + j] = 0.f;
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
     const int jo = 64 * jt + 16 * w + (lane & 15);
     const int b0 = 16 * m + 4 * (lane >> 4);
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) po[(size_t)(b0 + rg) * Hp + jo] = v[rg];
+    for (int rg = 0; rg < 4; ++rg) st_state(&po[(size_t)(b0 + rg) * Hp + jo], v[rg]);
   }
 }
 

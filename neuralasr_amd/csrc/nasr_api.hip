@@ -74,6 +74,7 @@ struct nasr_ctx {
   bool own_stream = false;
   hipStream_t side = nullptr;          // low-priority stream: weight-gradient GEMMs of layer l under BPTT of layer l-1
   bool overlap = true;
+  bool gemm_bf16 = true;               // bulk GEMMs on the bf16 matrix cores (fp32-accurate 3-way split), NASR_GEMM=f32 disables
   std::vector<hipEvent_t> ev_bptt, ev_wgrad;
   std::string err;
 
@@ -88,6 +89,8 @@ struct nasr_ctx {
   std::vector<int32_t> tf2int;          // TF flat index -> internal flat index
 
   float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *Uf = nullptr, *Ub = nullptr;
+  float* WxT = nullptr;                // per layer [D*N4][Ip]: transposed input weights (K-contiguous B operand)
+  std::vector<int64_t> off_wxt;
   int64_t adam_step = 0;
   float lr;
 
@@ -97,7 +100,7 @@ struct nasr_ctx {
   int64_t frames = 0;
   std::vector<int32_t> h_seq;
 
-  DevBuf feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, dgbuf2, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
+  DevBuf X0T, outT0, outT1, dGT, feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, dgbuf2, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
       rowmap, slabs, csws, amax, ids, lens, stage;
   std::vector<DevBuf> gates, outb, cbuf;
 
@@ -272,6 +275,10 @@ int repack(nasr_ctx* h) {
       const size_t o = k * (size_t)h->Hp * h->N4;
       launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
     }
+  if (h->gemm_bf16)
+    for (int l = 0; l < h->L; ++l)
+      launch_transpose(h->P + h->off_wx[l], h->WxT + h->off_wxt[l], h->Ip[l], h->D * h->N4, h->D * h->N4, h->Ip[l],
+                       h->st);
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
 }
@@ -309,6 +316,12 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->partial.ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
   ok &= h->dcstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
   ok &= h->dgbuf.ensure(R * D * N4 * 4, &grew);
+  if (h->gemm_bf16) {
+    ok &= h->X0T.ensure(R * h->Fp * 4, &grew);
+    ok &= h->outT0.ensure(R * D * Hp * 4, &grew);
+    ok &= h->outT1.ensure(R * D * Hp * 4, &grew);
+    ok &= h->dGT.ensure(R * D * N4 * 4, &grew);
+  }
   if (h->L > 1 && h->overlap) ok &= h->dgbuf2.ensure(R * D * N4 * 4, &grew);
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
@@ -415,6 +428,8 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
       HIPCHK(h, hipStreamSynchronize(h->st));
     }
     launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
+    if (h->gemm_bf16 && labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
+      launch_transpose(h->X0.as<float>(), h->X0T.as<float>(), T * Bp, h->Fp, h->Fp, T * Bp, h->st);
     HIPCHK(h, hipGetLastError());
   }
   h->resident = true;
@@ -493,14 +508,24 @@ int forward(nasr_ctx* h) {
   for (int l = 0; l < h->L; ++l) {
     {
       PhaseScope ps(h, PH_XPROJ);
-      GemmDesc g{};
-      g.A = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
-      g.B = h->P + h->off_wx[l];
-      g.C = h->gates[l].as<float>();
-      g.M = R; g.N = D * N4; g.K = h->Ip[l];
-      g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
-      g.a_col = false; g.b_col = false; g.a_rows = R; g.bias = h->P + h->off_bias[l]; g.split_k = 1;
-      launch_gemm(g, h->st);
+      const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
+      if (h->gemm_bf16) {
+        GemmNTDesc g{};
+        g.A = Xl; g.B = h->WxT + h->off_wxt[l]; g.C = h->gates[l].as<float>();
+        g.M = R; g.N = D * N4; g.K = h->Ip[l];
+        g.lda = h->Ip[l]; g.ldb = h->Ip[l]; g.ldc = D * N4;
+        g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+        launch_gemm_nt(g, h->st);
+      } else {
+        GemmDesc g{};
+        g.A = Xl;
+        g.B = h->P + h->off_wx[l];
+        g.C = h->gates[l].as<float>();
+        g.M = R; g.N = D * N4; g.K = h->Ip[l];
+        g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
+        g.a_col = false; g.b_col = false; g.a_rows = R; g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+        launch_gemm(g, h->st);
+      }
       HIPCHK(h, hipGetLastError());
     }
     {
@@ -610,6 +635,46 @@ int backward(nasr_ctx* h) {
       HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_bptt[l], 0));
       ws = h->side;
     }
+    const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
+    if (h->gemm_bf16) {
+      if (l > 0) {  // critical path first: dOut_{l-1} = dG * Wx^T (both operands K-contiguous as stored)
+        GemmNTDesc g{};
+        g.A = dG; g.B = h->P + h->off_wx[l]; g.C = h->dout.as<float>();
+        g.M = R; g.N = h->Ip[l]; g.K = D * N4;
+        g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp; g.split_k = 1;
+        launch_gemm_nt(g, h->st);
+      }
+      // K-contiguous copies of the operands whose contraction index is the row (time) index
+      float* tOut[2] = {h->outT0.as<float>(), h->outT1.as<float>()};
+      launch_transpose(dG, h->dGT.as<float>(), R, D * N4, D * N4, R, ws);
+      if (l == h->L - 1) launch_transpose(h->outb[l].as<float>(), tOut[l & 1], R, D * Hp, D * Hp, R, ws);
+      if (l > 0) launch_transpose(h->outb[l - 1].as<float>(), tOut[(l - 1) & 1], R, D * Hp, D * Hp, R, ws);
+      const float* XT = l == 0 ? h->X0T.as<float>() : tOut[(l - 1) & 1];
+      {  // dWx = X^T dG
+        GemmNTDesc g{};
+        g.A = XT; g.B = h->dGT.as<float>(); g.C = h->G + h->off_wx[l];
+        g.M = h->Ip[l]; g.N = D * N4; g.K = R;
+        g.lda = R; g.ldb = R; g.ldc = D * N4;
+        g.split_k = gemm_pick_split(g.M, g.N, g.K);
+        g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+        if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+        launch_gemm_nt(g, ws);
+      }
+      launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
+      for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
+        GemmNTDesc g{};
+        g.A = tOut[l & 1] + (size_t)d * Hp * R;
+        g.B = h->dGT.as<float>() + (size_t)d * N4 * R;
+        g.C = h->G + h->off_u[(size_t)l * D + d];
+        g.M = Hp; g.N = N4; g.K = R;
+        g.lda = R; g.ldb = R; g.ldc = N4;
+        g.a_kshift = d == 0 ? -Bp : Bp;
+        g.split_k = gemm_pick_split(g.M, g.N, g.K);
+        g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+        if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+        launch_gemm_nt(g, ws);
+      }
+    } else {
     if (l > 0) {  // critical path first: gradient wrt the layer input = the layer below's output
       GemmDesc g{};
       g.A = dG; g.B = h->P + h->off_wx[l]; g.C = h->dout.as<float>();
@@ -618,7 +683,6 @@ int backward(nasr_ctx* h) {
       g.b_col = true; g.a_rows = R; g.split_k = 1;
       launch_gemm(g, h->st);
     }
-    const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
     {  // dWx = X^T dG
       GemmDesc g{};
       g.A = Xl; g.B = dG; g.C = h->G + h->off_wx[l];
@@ -643,6 +707,7 @@ int backward(nasr_ctx* h) {
       g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
       if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
       launch_gemm(g, ws);
+    }
     }
     if (ws != h->st) HIPCHK(h, hipEventRecord(h->ev_wgrad[l], ws));
     HIPCHK(h, hipGetLastError());
@@ -725,6 +790,18 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     h->own_stream = true;
   }
   if (build_layout(h) != NASR_OK) return bail(NASR_ERR_ARG, h->err);
+  {
+    const char* e = getenv("NASR_GEMM");
+    h->gemm_bf16 = !(e && std::string(e) == "f32");
+    int64_t o = 0;
+    h->off_wxt.resize(h->L);
+    for (int l = 0; l < h->L; ++l) {
+      h->off_wxt[l] = o;
+      o += (int64_t)h->Ip[l] * h->D * h->N4;
+    }
+    if (h->gemm_bf16 && hipMalloc(&h->WxT, (size_t)o * 4) != hipSuccess)
+      return bail(NASR_ERR_HIP, "hipMalloc of transposed weights failed");
+  }
   const size_t nb = (size_t)h->np_int * 4;
   const size_t ub = (size_t)h->L * h->D * h->Hp * h->N4 * 4;
   if (hipMalloc(&h->P, nb) != hipSuccess || hipMalloc(&h->M, nb) != hipSuccess || hipMalloc(&h->V, nb) != hipSuccess ||
@@ -775,9 +852,9 @@ int nasr_destroy(nasr_handle h) {
   for (hipEvent_t e : h->ev_bptt) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_wgrad) (void)hipEventDestroy(e);
   drop_graphs(h);
-  for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub})
+  for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub, h->WxT})
     if (p) (void)hipFree(p);
-  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->dgbuf2, &h->logits, &h->logz,
+  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->dgbuf2, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
     b->release();
