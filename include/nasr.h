@@ -126,6 +126,14 @@ int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len
  * library's padded internal layout (identical on every rank; padding elements are always 0). */
 int nasr_upload_batch(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
                       const int32_t* label_len, int B, int T, int Lmax);
+/* Same, but the context stacking of utils.py:8-21 (include_context) happens on the device: `centre` is the
+ * un-stacked [B,T,numcep] slice (for features made by preprocess_mfcc.py: columns [numcontext*numcep,
+ * (numcontext+1)*numcep) of the stacked array), pad_value[b] the value the stacked array holds in the
+ * out-of-utterance context frames of utterance b (its element [b,0,0]).  Needs feature_size ==
+ * (2*numcontext+1)*numcep.  Moves 1/(2*numcontext+1) of the bytes over PCIe. */
+int nasr_upload_batch_context(nasr_handle h, const float* centre, const float* pad_value, int numcontext, int numcep,
+                              const int32_t* seq_len, const int32_t* labels, const int32_t* label_len, int B, int T,
+                              int Lmax);
 int nasr_compute_grads(nasr_handle h);          /* forward+CTC+backward on the resident batch (async) */
 void* nasr_grad_device_ptr(nasr_handle h);
 int64_t nasr_grad_device_count(nasr_handle h);

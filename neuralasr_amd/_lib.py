@@ -23,7 +23,7 @@ SYMBOLS = [
     'nasr_get_adam_state', 'nasr_set_learning_rate', 'nasr_train_step', 'nasr_forward', 'nasr_logit_frames',
     'nasr_loss', 'nasr_loss_and_grads', 'nasr_greedy_decode', 'nasr_upload_batch', 'nasr_compute_grads',
     'nasr_grad_device_ptr', 'nasr_grad_device_count', 'nasr_apply_adam', 'nasr_get_grads', 'nasr_set_grads',
-    'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_ctc_beam_search', 'nasr_get_loss', 'nasr_resident_frames',
+    'nasr_upload_batch_context', 'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_ctc_beam_search', 'nasr_get_loss', 'nasr_resident_frames',
     'nasr_set_profiling', 'nasr_get_phase_times', 'nasr_set_graph_mode',
 ]
 
@@ -88,6 +88,7 @@ def load():
         'nasr_loss_and_grads': (c_int, [H, fp, ip, ip, ip, c_int, c_int, c_int, fp, fp, fp]),
         'nasr_greedy_decode': (c_int, [H, fp, ip, c_int, c_int, ip, ip]),
         'nasr_upload_batch': (c_int, [H, fp, ip, ip, ip, c_int, c_int, c_int]),
+        'nasr_upload_batch_context': (c_int, [H, fp, fp, c_int, c_int, ip, ip, ip, c_int, c_int, c_int]),
         'nasr_compute_grads': (c_int, [H]),
         'nasr_grad_device_ptr': (c_void_p, [H]),
         'nasr_grad_device_count': (c_int64, [H]),

@@ -51,6 +51,8 @@ struct LstmDims {
   int T, B, Bp, H, Hp, D;   // D directions
 };
 void launch_pack_feats(const float* feats_bm, float* X0, int B, int Bp, int T, int F, int Fp, hipStream_t st);
+void launch_expand_context(const float* centre, const float* pad, const int* seq_len, float* X0, int B, int Bp, int T,
+                           int ctx, int ncep, int Fp, hipStream_t st);
 // repack canonical U [Hp][N4] of every (layer,dir) into the forward / backward MFMA B-operand images
 void launch_repack_u(const float* U, float* Uf, float* Ub, int Hp, hipStream_t st);
 void launch_lstm_fwd_step(const LstmDims& dm, int s, const float* Uf, const float* hin, float* hout, float* gates,

@@ -85,6 +85,36 @@ void launch_pack_feats(const float* feats_bm, float* X0, int B, int Bp, int T, i
   hipLaunchKernelGGL(pack_feats_kernel, dim3(T * Bp), dim3(256), 0, st, feats_bm, X0, B, Bp, T, F, Fp);
 }
 
+// include_context on the device (utils.py:8-21): the caller ships only the centre frame [B][T][numcep]; every
+// time-major row gets its (2*ctx+1)-frame window, out-of-range frames of an utterance filled with that
+// utterance's pad value (0 before the utterance-level normalisation of utils.py:29, (0-mean)/std after it),
+// frames past seq_len zero (dataset.py:75-77).  21x fewer bytes over PCIe for numcontext = 10.
+__global__ __launch_bounds__(256) void expand_context_kernel(const float* __restrict__ centre,
+                                                             const float* __restrict__ pad, const int* __restrict__ seq_len,
+                                                             float* __restrict__ x, int B, int Bp, int T, int ctx,
+                                                             int ncep, int Fp) {
+  const int r = blockIdx.x;  // t*Bp + b
+  const int t = r / Bp, b = r % Bp;
+  float* dst = x + (size_t)r * Fp;
+  const int len = b < B ? seq_len[b] : 0;
+  const int F = (2 * ctx + 1) * ncep;
+  for (int i = threadIdx.x; i < Fp; i += blockDim.x) {
+    float v = 0.f;
+    if (i < F && t < len) {
+      const int wdw = i / ncep, c = i - wdw * ncep;
+      const int ts = t + wdw - ctx;
+      v = (ts >= 0 && ts < len) ? centre[((size_t)b * T + ts) * ncep + c] : pad[b];
+    }
+    dst[i] = v;
+  }
+}
+
+void launch_expand_context(const float* centre, const float* pad, const int* seq_len, float* X0, int B, int Bp, int T,
+                           int ctx, int ncep, int Fp, hipStream_t st) {
+  hipLaunchKernelGGL(expand_context_kernel, dim3(T * Bp), dim3(256), 0, st, centre, pad, seq_len, X0, B, Bp, T, ctx,
+                     ncep, Fp);
+}
+
 // ------------------------------------------------------------------ recurrent weight repack
 // U [Hp][N4] (row k = h unit, col n = 4*j+g) ->
 //   Uf [N4/16 tiles][Hp/16][64][4] : Uf[tile][q][l][i] = U[16q + 4*(l>>4) + i][16*tile + (l&15)]

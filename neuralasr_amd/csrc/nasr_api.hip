@@ -378,8 +378,11 @@ int validate_batch(nasr_ctx* h, const int32_t* seq_len, const int32_t* labels, c
 }
 
 int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_t* labels, const int32_t* label_len,
-           int B, int T, int Lmax) {
-  if (!feats || !seq_len) return h->fail(NASR_ERR_ARG, "null input buffer");
+           int B, int T, int Lmax, const float* centre = nullptr, const float* pad_value = nullptr, int ctx = 0,
+           int ncep = 0) {
+  if ((!feats && !centre) || !seq_len) return h->fail(NASR_ERR_ARG, "null input buffer");
+  if (centre && (!pad_value || ctx < 0 || ncep < 1 || (2 * ctx + 1) * ncep != h->F))
+    return h->fail(NASR_ERR_ARG, "context upload: feature_size must equal (2*numcontext+1)*numcep");
   if (labels && !label_len) return h->fail(NASR_ERR_ARG, "labels without label_len");
   int rc = validate_batch(h, seq_len, labels, label_len, B, T, Lmax);
   if (rc) return rc;
@@ -402,7 +405,13 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
   }
   {
     PhaseScope ps(h, PH_PACK);
-    HIPCHK(h, hipMemcpyAsync(h->feats_bm.p, feats, (size_t)B * T * h->F * 4, hipMemcpyHostToDevice, h->st));
+    if (centre) {   // feats_bm is large enough: B*T*F >= B*T*numcep + B
+      HIPCHK(h, hipMemcpyAsync(h->feats_bm.p, centre, (size_t)B * T * ncep * 4, hipMemcpyHostToDevice, h->st));
+      HIPCHK(h, hipMemcpyAsync(h->feats_bm.as<float>() + (size_t)B * T * ncep, pad_value, (size_t)B * 4,
+                               hipMemcpyHostToDevice, h->st));
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->feats_bm.p, feats, (size_t)B * T * h->F * 4, hipMemcpyHostToDevice, h->st));
+    }
     HIPCHK(h, hipMemcpyAsync(h->seq.p, h->h_seq.data(), (size_t)Bp * 4, hipMemcpyHostToDevice, h->st));
     if (labels) {
       std::vector<int32_t> ll((size_t)Bp, 0);
@@ -427,7 +436,11 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
       HIPCHK(h, hipMemcpyAsync(h->rowmap.p, map.data(), map.size() * 4, hipMemcpyHostToDevice, h->st));
       HIPCHK(h, hipStreamSynchronize(h->st));
     }
-    launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
+    if (centre)
+      launch_expand_context(h->feats_bm.as<float>(), h->feats_bm.as<float>() + (size_t)B * T * ncep, h->seq.as<int>(),
+                            h->X0.as<float>(), B, Bp, T, ctx, ncep, h->Fp, h->st);
+    else
+      launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
     if (h->gemm_bf16 && labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
       launch_transpose(h->X0.as<float>(), h->X0T.as<float>(), T * Bp, h->Fp, h->Fp, T * Bp, h->st);
     HIPCHK(h, hipGetLastError());
@@ -952,6 +965,14 @@ int nasr_upload_batch(nasr_handle h, const float* feats, const int32_t* seq_len,
                       const int32_t* label_len, int B, int T, int Lmax) {
   if (!h) return NASR_ERR_ARG;
   return upload(h, feats, seq_len, labels, label_len, B, T, Lmax);
+}
+
+int nasr_upload_batch_context(nasr_handle h, const float* centre, const float* pad_value, int numcontext, int numcep,
+                              const int32_t* seq_len, const int32_t* labels, const int32_t* label_len, int B, int T,
+                              int Lmax) {
+  if (!h) return NASR_ERR_ARG;
+  if (!centre) return h->fail(NASR_ERR_ARG, "null input buffer");
+  return upload(h, nullptr, seq_len, labels, label_len, B, T, Lmax, centre, pad_value, numcontext, numcep);
 }
 
 int nasr_compute_grads(nasr_handle h) {

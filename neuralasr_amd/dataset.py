@@ -84,6 +84,36 @@ class DataSet:
         labels = [np.pad(l, (0, max_label - n), 'constant', constant_values=(pad, pad)) for _, l, _, n in items]
         return np.asarray(mfccs), np.asarray(labels), [s for _, _, s, _ in items], [n for _, _, _, n in items]
 
+    # ------------------------------------------------------------------ asynchronous input pipeline
+    def prefetch(self, depth=2):
+        """Iterate the remaining batches of this epoch while a background thread unpickles and pads the next
+        `depth` of them (the reference loads synchronously inside the timed loop, train.py:23-25).  Batch
+        composition and order are exactly get_next_batch()'s; with rand_shift > 0 the augmentation draws from
+        np.random in the loader thread, so the draws stay in batch order."""
+        import queue
+        import threading
+        q = queue.Queue(maxsize=max(1, depth))
+        stop = object()
+
+        def worker():
+            try:
+                while self.has_more_batches():
+                    q.put(self.get_next_batch())
+                q.put(stop)
+            except BaseException as exc:      # surface loader errors in the consumer
+                q.put(exc)
+
+        t = threading.Thread(target=worker, name='nasr-prefetch', daemon=True)
+        t.start()
+        while True:
+            item = q.get()
+            if item is stop:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+        t.join()
+
     def get_feature_shape(self):
         return [self.config.batch_size, None, self.config.feature_size]
 

@@ -161,6 +161,28 @@ class Engine:
         feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
         self._ck(self.lib.nasr_upload_batch(self.h, _fp(feats), _ip(seq), _ip(labels), _ip(ll), B, T, Lmax))
 
+    def upload_batch_context(self, feats, seq_len, labels, label_len, numcontext, numcep):
+        """Upload context-stacked features [B,T,(2*numcontext+1)*numcep] as their centre slice and rebuild the
+        stacking on the device (include_context, utils.py:8-21).  Returns False (nothing uploaded) when the
+        array does not have that structure (e.g. rand_shift cropped it), so the caller can upload it whole."""
+        feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
+        w = 2 * numcontext + 1
+        if numcontext < 1 or feats.shape[2] != w * numcep:
+            return False
+        pad = np.ascontiguousarray(feats[:, 0, 0])
+        rs = np.random.RandomState(0)
+        for _ in range(48):                       # spot-check the window structure before trusting it
+            b = rs.randint(B)
+            t, k = rs.randint(seq[b]), rs.randint(w)
+            ts = t + k - numcontext
+            want = feats[b, ts, numcontext * numcep:(numcontext + 1) * numcep] if 0 <= ts < seq[b] else pad[b]
+            if not np.array_equal(feats[b, t, k * numcep:(k + 1) * numcep], np.broadcast_to(want, (numcep,))):
+                return False
+        centre = np.ascontiguousarray(feats[:, :, numcontext * numcep:(numcontext + 1) * numcep])
+        self._ck(self.lib.nasr_upload_batch_context(self.h, _fp(centre), _fp(pad), int(numcontext), int(numcep),
+                                                    _ip(seq), _ip(labels), _ip(ll), B, T, Lmax))
+        return True
+
     def compute_grads(self):
         self._ck(self.lib.nasr_compute_grads(self.h))
 

@@ -50,6 +50,7 @@ class HipNetwork(Network):
     decoder = 'beam'                         # validate / evaluate / decode: tf.nn.ctc_beam_search_decoder defaults
     train_ler_decoder = 'greedy'             # mean_ler of train(): greedy on the step's own logits
     beam_width = 100
+    device_context = True                    # rebuild include_context's stacking on the GPU (1/(2c+1) of the H2D bytes)
 
     def __init__(self, config, fortraining=False):
         Network.__init__(self)
@@ -155,7 +156,10 @@ class HipNetwork(Network):
         losses, lers, gsum = [], [], None
         for k in mine:
             f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, k)
-            self.engine.upload_batch(f, s, l, ll)
+            ctx = getattr(self.config, 'numcontext', 0)
+            if not (self.device_context and ctx > 0 and
+                    self.engine.upload_batch_context(f, s, l, ll, ctx, self.config.numcep)):
+                self.engine.upload_batch(f, s, l, ll)
             self.engine.compute_grads()
             losses.append(self.engine.get_loss())
             hyps = (self._decode(f, s, 'beam') if self.train_ler_decoder == 'beam'

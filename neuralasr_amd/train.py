@@ -14,15 +14,21 @@ from .logger import get_logger
 logger = get_logger()
 
 
-def train_model(dataTrain, datavalid, config):
+def train_model(dataTrain, datavalid, config, prefetch=2):
     logger.info('Batch Dimensions: ' + str(dataTrain.get_feature_shape()))
     logger.info('Label Dimensions: ' + str(dataTrain.get_label_shape()))
     network = config.load_network(fortraining=True)
     spent, loss_sum, ler_sum = 0.0, 0.0, 0.0     # train_time_sec is never reset (train.py:20,26,34)
     for _ in range(config.epochs):
-        while dataTrain.has_more_batches():
+        batches = dataTrain.prefetch(prefetch) if prefetch else iter(dataTrain.get_next_batch, None)
+        while True:
             t0 = time.time()
-            mfccs, labels, seq_len, labels_len = dataTrain.get_next_batch()
+            if not prefetch and not dataTrain.has_more_batches():
+                break
+            try:
+                mfccs, labels, seq_len, labels_len = next(batches)
+            except StopIteration:
+                break
             loss, mean_ler = network.train(mfccs, labels, seq_len, labels_len)
             spent += time.time() - t0
             loss_sum += loss

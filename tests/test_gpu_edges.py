@@ -124,3 +124,35 @@ def test_hidden_sizes_cover_every_template_path(H, layers, bi):
     spec = O.ModelSpec(9, H, layers, bi, 'concat' if bi else 'none', 6)
     feats, seq_len, labels, label_len = O.synth_batch(spec, 4, 6, seed=H, var_len=True, Lmin=1, Lmax=2)
     check(spec, feats, seq_len, labels, label_len)
+
+
+def test_device_side_context_stacking_is_bitwise_the_host_stacking():
+    """include_context (utils.py:8-21) + the utterance-level normalisation (utils.py:29) done on the host, vs
+    the same batch uploaded as its centre slice and stacked in HBM."""
+    from neuralasr_amd import utils
+    ctx, ncep, B, T = 3, 5, 4, 23
+    spec = O.ModelSpec((2 * ctx + 1) * ncep, 24, 1, True, 'stack_reshape', 6)
+    rs = np.random.RandomState(4)
+    seq_len = np.array([23, 17, 9, 23], np.int32)
+    feats = np.zeros((B, T, spec.feature_size), np.float32)
+    for b in range(B):
+        raw = rs.randn(seq_len[b], ncep).astype(np.float32)
+        st = utils.include_context(raw, ctx, ncep)
+        st = ((st - st.mean()) / st.std()).astype(np.float32)          # pad frames become (0-mean)/std
+        feats[b, :seq_len[b]] = st
+    _, _, labels, label_len = O.synth_batch(spec, B, 9, seed=2, Lmin=1, Lmax=3)
+    e = engine_for(spec)
+    e.set_params(O.flatten(O.init_params(spec, seed=5)))
+    e.upload_batch(feats, seq_len, labels, label_len)
+    e.compute_grads()
+    l1, g1 = e.get_loss(), e.get_grads()
+    assert e.upload_batch_context(feats, seq_len, labels, label_len, ctx, ncep) is True
+    e.compute_grads()
+    l2, g2 = e.get_loss(), e.get_grads()
+    assert l1 == l2
+    np.testing.assert_array_equal(g1, g2)
+    # a batch without the window structure is refused (caller falls back to the plain upload)
+    broken = feats.copy()
+    broken[:, :, :ncep] = rs.randn(B, T, ncep)
+    assert e.upload_batch_context(broken, seq_len, labels, label_len, ctx, ncep) is False
+    e.close()

@@ -152,3 +152,27 @@ def test_sparse_tuple_from_matches_survey_golden():
     assert i.tolist() == [[0, 0], [0, 1], [1, 0]] and i.dtype == np.int64
     assert v.tolist() == [1, 2, 3] and v.dtype == np.int32
     assert s.tolist() == [2, 2] and s.dtype == np.int64
+
+
+def test_prefetch_yields_the_same_batches_in_order(toy_config):
+    c = Config(toy_config, True)
+    a, b = DataSet(c.train_input, c), DataSet(c.train_input, c)
+    got = list(b.prefetch(depth=2))
+    want = []
+    while a.has_more_batches():
+        want.append(a.get_next_batch())
+    assert len(got) == len(want) == 2 and not b.has_more_batches()
+    for (m1, l1, s1, n1), (m2, l2, s2, n2) in zip(got, want):
+        np.testing.assert_array_equal(m1, m2)
+        np.testing.assert_array_equal(l1, l2)
+        assert [int(x) for x in s1] == [int(x) for x in s2] and n1 == n2
+    b.reset_epoch()
+    assert len(list(b.prefetch())) == 2          # a fresh epoch can be prefetched again
+
+
+def test_prefetch_surfaces_loader_errors(toy_config, tmp_path):
+    c = Config(toy_config, True)
+    scp = tmp_path / 'bad.scp'
+    scp.write_text('does_not_exist.pkl\n')
+    with pytest.raises(FileNotFoundError):
+        list(DataSet(str(scp), c).prefetch())
