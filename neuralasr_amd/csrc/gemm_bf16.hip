@@ -18,8 +18,15 @@
 // default for the input-to-hidden, input-gradient and weight-gradient GEMMs (NASR_GEMM=f32 selects gemm.hip):
 // 3x500 step 19.0 -> 17.1 ms.  The projection GEMMs keep gemm.hip (row gather/scatter maps).  The on-the-fly
 // split (~180 VALU ops + 48 KB of ds_write_b64 per k-tile per block) is what keeps it from the 2.7x the MFMA
-// count alone would give.
+// count alone would give: ablations (NASR_NT_ABL, xproj 8000x4096x1024, 0.49 ms) put the six MFMAs at 40 %, the
+// LDS stores at 40 % and the split arithmetic at 13 % of the time, nearly additive.  Tried and measured slower:
+// issuing the split inside the MFMA stream (spills, 0.50 ms) and a producer/consumer warp-specialised 8-wave
+// form with double-buffered LDS (160 KB => one block per CU, 0.64 ms).
 #include "kernels.h"
+
+#ifndef NASR_NT_ABL
+#define NASR_NT_ABL 0   // tools/gemmbench ablations: 1 cheap split (no subtraction), 2 one MFMA instead of six, 4 no LDS stores
+#endif
 
 namespace nasr {
 
@@ -45,6 +52,7 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& p1, bf16x4& p2, b
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const __bf16 h1 = (__bf16)x[i];
+    if (NASR_NT_ABL & 1) { p1[i] = h1; p2[i] = h1; p3[i] = h1; continue; }
     const float r1 = x[i] - (float)h1;
     const __bf16 h2 = (__bf16)r1;
     const float r2 = r1 - (float)h2;
@@ -108,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x6_kernel(GemmNTParams p) 
       const int idx = tid + 256 * j, row = idx >> 3, kq = idx & 7;
       bf16x4 p1, p2, p3;
       split3(ra[j], p1, p2, p3);
+      if ((NASR_NT_ABL & 4) && kt > 0) continue;
       *reinterpret_cast<bf16x4*>(&As[0][row][4 * kq]) = p1;
       *reinterpret_cast<bf16x4*>(&As[1][row][4 * kq]) = p2;
       *reinterpret_cast<bf16x4*>(&As[2][row][4 * kq]) = p3;
@@ -134,11 +143,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x6_kernel(GemmNTParams p) 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           f32x16 c = acc[i][j];       // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          if (!(NASR_NT_ABL & 2)) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
           acc[i][j] = c;
         }
@@ -189,8 +200,8 @@ void launch_gemm_nt(const GemmNTDesc& g, hipStream_t st) {
   const int per = (kt + p.split_k - 1) / p.split_k;
   p.kchunk = per * TBK;
   p.split_k = (kt + per - 1) / per;
-  dim3 grid((g.N + TBN - 1) / TBN, (g.M + TBM - 1) / TBM, p.split_k), block(256);
-  hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, grid, block, 0, st, p);
+  dim3 grid((g.N + TBN - 1) / TBN, (g.M + TBM - 1) / TBM, p.split_k);
+  hipLaunchKernelGGL(gemm_nt_bf16x6_kernel, grid, dim3(256), 0, st, p);
   if (p.split_k > 1) {
     const int64_t n4 = (int64_t)g.M * g.N / 4;
     int blocks = (int)((n4 + 255) / 256);
