@@ -118,7 +118,13 @@ def main():
 
     spec, wname = workload_spec(args.workload)
     B, T = args.batch, args.frames
-    stream = torch.cuda.current_stream().cuda_stream
+    # One explicit (non-default) torch stream carries everything: the engine launches on it and torch.distributed
+    # orders its RCCL work against the CURRENT stream, so kernels -> all-reduce -> Adam need no host sync.
+    # (The legacy default stream cannot be used: it is not capturable and an engine-owned stream would not be
+    # ordered with the collective.)
+    tstream = torch.cuda.Stream(device=local)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     eng = Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
                  learning_rate=1e-4, device_id=local, stream=stream)
     eng.set_graph_mode(not args.no_graph)

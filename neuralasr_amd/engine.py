@@ -33,6 +33,9 @@ class Engine:
         self.cfg = _lib.ModelCfg(int(feature_size), int(hidden), int(num_layers), int(bool(bidirectional)), merge_id,
                                  int(num_classes), float(forget_bias), float(learning_rate), float(beta1),
                                  float(beta2), float(epsilon))
+        if stream is not None and int(stream) == 0:
+            raise ValueError('stream 0 (the legacy default stream) cannot carry the engine: pass a created stream '
+                             '(e.g. torch.cuda.Stream().cuda_stream) or None for an engine-owned one')
         self.h = c_void_p()
         rc = self.lib.nasr_create(byref(self.cfg), int(device_id), c_void_p(stream) if stream else None, byref(self.h))
         if rc != 0:

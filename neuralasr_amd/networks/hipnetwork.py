@@ -61,9 +61,13 @@ class HipNetwork(Network):
         device = int(os.environ.get('LOCAL_RANK', '0')) if self.coll.world > 1 else 0
         stream = None
         if self.coll.world > 1:
+            # a dedicated non-default torch stream, made current: the engine launches on it and the RCCL
+            # all-reduce is ordered against it (the legacy default stream is neither capturable nor shared)
             import torch
             torch.cuda.set_device(device)
-            stream = torch.cuda.current_stream().cuda_stream
+            self._torch_stream = torch.cuda.Stream(device=device)
+            torch.cuda.set_stream(self._torch_stream)
+            stream = self._torch_stream.cuda_stream
         self.logger.info('Initializing network for %s.' % ('training' if fortraining else 'inference'))
         self.engine = Engine(config.feature_size, self.num_hidden, self.num_layers, self.bidirectional, self.merge,
                              self.num_classes, learning_rate=config.learningrate, device_id=device, stream=stream)

@@ -138,3 +138,51 @@ def test_train_model_loop_end_to_end(tmp_path, caplog):
     assert costs[-1] < costs[0]                                   # it learns the toy set
     assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(cfg.model_dir, 'model-*.npz'))) == \
         ['model-2.npz', 'model-4.npz', 'model-6.npz']
+
+
+def test_rccl_path_at_world_one_orders_with_the_engine_stream(tmp_path):
+    """The data-parallel step (compute_grads -> all_reduce on the aliased device buffer -> apply_adam(1/n)) under
+    a real NCCL(RCCL) process group of one rank must equal the plain step bit for bit, and the torch tensor
+    must ALIAS the engine's gradient buffer."""
+    import torch
+    import torch.distributed as dist
+    from neuralasr_amd.engine import Engine
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        spec = O.ModelSpec(20, 48, 2, True, 'concat', 11)
+        feats, seq_len, labels, label_len = O.synth_batch(spec, 8, 21, seed=3, var_len=True, Lmin=1, Lmax=5)
+        p0 = O.flatten(O.init_params(spec, seed=8)).astype(np.float32)
+        ref = Engine(20, 48, 2, True, 'concat', 11, learning_rate=1e-3)
+        ref.set_params(p0)
+        for _ in range(3):
+            ref.train_step(feats, seq_len, labels, label_len)
+        ts = torch.cuda.Stream()
+        torch.cuda.set_stream(ts)
+        with pytest.raises(ValueError):
+            Engine(20, 48, 2, True, 'concat', 11, stream=0)
+        e = Engine(20, 48, 2, True, 'concat', 11, learning_rate=1e-3, stream=ts.cuda_stream)
+        e.set_params(p0)
+        gt = e.grad_tensor()
+        assert gt.numel() == e.grad_device_ptr()[1] and gt.data_ptr() == e.grad_device_ptr()[0]
+        for _ in range(3):
+            e.upload_batch(feats, seq_len, labels, label_len)
+            e.compute_grads()
+            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+            e.apply_adam(1.0)
+        np.testing.assert_array_equal(e.get_params(), ref.get_params())
+        # aliasing: scaling the torch view scales what the engine hands back
+        e.upload_batch(feats, seq_len, labels, label_len)
+        e.compute_grads()
+        g1 = e.get_grads()
+        gt.mul_(2.0)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(e.get_grads(), 2 * g1)
+        e.close()
+        ref.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dist.destroy_process_group()
