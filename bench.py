@@ -64,24 +64,44 @@ def step_kernel_bytes(spec, B):
 
 
 def cpu_baseline(spec, B, seed):
-    """The fp64 NumPy oracle (kind "port": our CPU restatement of the TF graph; TensorFlow itself is not
-    in this image — SURVEY.md D8) timed on a bounded sample of the same workload: same net, same batch
-    size, T cut so that one forward+backward takes ~10-30 s."""
+    """The CPU restatement timed on the GPU box's host cores (kind "port": TensorFlow itself is not in this image,
+    SURVEY.md D8): oracle/cref/nasr_cref.c (plain C + OpenMP, fp32, the same forward + CTC + backward, Adam
+    excluded) on a bounded sample of the same workload — same net and batch size, T sized by a short probe so the
+    timed call takes ~10-20 s.  Falls back to the fp64 NumPy oracle if the C library cannot be built."""
     from oracle import nasr_oracle as O
+    try:
+        from oracle import cref
+        threads = cref.num_threads()
+        params = O.flatten(O.init_params(spec, seed=1)).astype(np.float32)
+
+        def run(T):
+            feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=seed)
+            t0 = time.time()
+            cref.loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+            return time.time() - t0, int(seq_len.sum())
+        run(8)                                         # warm the thread pool / page in
+        dt, fr = run(24)
+        Tc = int(max(32, min(500, 24 * 14.0 / max(dt, 1e-3))))
+        dt, fr = run(Tc)
+        return {'value': fr / dt, 'unit': 'frames/s', 'cores': int(threads), 'kind': 'port',
+                'sample': f'oracle/cref/nasr_cref.c (C + OpenMP, fp32), 1 fwd+CTC+bwd step of the same net at B={B}, '
+                          f'T={Tc} ({fr} frames, {dt:.1f} s); Adam excluded'}
+    except Exception as exc:                           # noqa: BLE001 - baseline must not take the bench down
+        note = f'C restatement unavailable ({type(exc).__name__}); '
     try:
         from threadpoolctl import threadpool_info
         thr = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
     except Exception:
         thr = os.cpu_count() or 1
-    Tc = 200 if spec.num_layers > 1 else 400     # ~10-20 s of CPU work on the GPU box's host
+    Tc = 200 if spec.num_layers > 1 else 400
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, Tc, seed=seed)
     params = O.init_params(spec, seed=1)
     t0 = time.time()
     O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
     dt = time.time() - t0
     return {'value': float(seq_len.sum() / dt), 'unit': 'frames/s', 'cores': int(thr), 'kind': 'port',
-            'sample': f'fp64 NumPy oracle, 1 fwd+bwd step of the same net at B={B}, T={Tc} ({int(seq_len.sum())} frames, '
-                      f'{dt:.1f} s); Adam excluded'}
+            'sample': note + f'fp64 NumPy oracle, 1 fwd+bwd step of the same net at B={B}, T={Tc} '
+                             f'({int(seq_len.sum())} frames, {dt:.1f} s); Adam excluded'}
 
 
 def main():

@@ -1,0 +1,68 @@
+"""ctypes view of the C/OpenMP restatement (oracle/cref/nasr_cref.c).  Test infrastructure only: imported by tests/
+and by bench.py's cpu_baseline leg."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build_cref
+
+MERGE = {'none': 0, 'stack_reshape': 1, 'concat': 2}
+
+
+class Spec(ctypes.Structure):
+    _fields_ = [('feature_size', ctypes.c_int32), ('hidden', ctypes.c_int32), ('num_layers', ctypes.c_int32),
+                ('bidirectional', ctypes.c_int32), ('merge', ctypes.c_int32), ('num_classes', ctypes.c_int32),
+                ('forget_bias', ctypes.c_float)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        path = build_cref.OUT if os.path.exists(build_cref.OUT) else build_cref.build()
+        lib = ctypes.CDLL(path)
+        fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+        lib.cref_param_count.restype = ctypes.c_int64
+        lib.cref_param_count.argtypes = [ctypes.POINTER(Spec)]
+        lib.cref_num_threads.restype = ctypes.c_int
+        lib.cref_loss_and_grads.restype = ctypes.c_int
+        lib.cref_loss_and_grads.argtypes = [ctypes.POINTER(Spec), fp, fp, ip, ip, ip, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, fp, fp, fp, fp]
+        _lib = lib
+    return _lib
+
+
+def num_threads():
+    return int(load().cref_num_threads())
+
+
+def loss_and_grads(spec, flat_params, feats, seq_len, labels, label_len, want_grads=True, want_logits=False):
+    """spec: oracle.nasr_oracle.ModelSpec.  Returns (loss, nll [B], grads flat | None, logits [T',B,C] | None)."""
+    lib = load()
+    cs = Spec(spec.feature_size, spec.hidden, spec.num_layers, int(spec.bidirectional), MERGE[spec.merge],
+              spec.num_classes, float(spec.forget_bias))
+    P = np.ascontiguousarray(flat_params, np.float32)
+    assert P.size == lib.cref_param_count(ctypes.byref(cs))
+    X = np.ascontiguousarray(feats, np.float32)
+    B, T, _ = X.shape
+    sl = np.ascontiguousarray(seq_len, np.int32)
+    lab = np.ascontiguousarray(labels, np.int32).reshape(B, -1)
+    ll = np.ascontiguousarray(label_len, np.int32)
+    loss = ctypes.c_float()
+    nll = np.zeros(B, np.float32)
+    g = np.zeros(P.size, np.float32) if want_grads else None
+    Tp = spec.logit_frames(T)
+    lg = np.zeros((Tp, B, spec.num_classes), np.float32) if want_logits else None
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+    rc = lib.cref_loss_and_grads(ctypes.byref(cs), P.ctypes.data_as(fp), X.ctypes.data_as(fp), sl.ctypes.data_as(ip),
+                                 lab.ctypes.data_as(ip), ll.ctypes.data_as(ip), B, T, lab.shape[1], ctypes.byref(loss),
+                                 nll.ctypes.data_as(fp), g.ctypes.data_as(fp) if want_grads else None,
+                                 lg.ctypes.data_as(fp) if want_logits else None)
+    if rc == -3:
+        raise ValueError('Not enough time for target transition sequence')
+    if rc != 0:
+        raise RuntimeError('cref_loss_and_grads failed: %d' % rc)
+    return float(loss.value), nll, g, lg

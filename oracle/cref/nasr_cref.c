@@ -1,0 +1,407 @@
+/* nasr_cref.c — plain C (OpenMP) restatement of NeuralASR's CTC training step, fp32 with an fp64 CTC lattice.
+ *
+ * TEST INFRASTRUCTURE ONLY: a second CPU checker beside oracle/nasr_oracle.py and the timed `cpu_baseline`
+ * of bench.py.  Nothing under neuralasr_amd/ links or loads it.  PARITY STATUS: unpinned against TensorFlow
+ * (not in this image; the reference ships no fixtures for this path); pinned against the NumPy oracle, which is
+ * pinned by alignment enumeration, finite differences and torch (tests/test_oracle_pins.py, tests/test_cref.py).
+ *
+ * Reference call sites followed (relative to /root/reference):
+ *   networks/bilstm_ctc_net.py:17-48   BasicLSTMCell x2 in bidirectional_dynamic_rnn, stack-reshape, W/b, [2T,B,C]
+ *   networks/lstm_ctc_net.py:17-43     MultiRNNCell of LSTMCell, dynamic_rnn
+ *   networks/tfnetwork.py:58-59        tf.nn.ctc_loss + reduce_mean
+ * TF op semantics: SURVEY.md Appendix A.1-A.4 (gate order i,j,f,o; forget_bias inside the sigmoid; zero output and
+ * carried state past seq_len; bw direction over reverse_sequence; blank = C-1; beta excludes the emission at t).
+ *
+ * Parameter / gradient vectors use TF variable order: per layer (fw kernel [I+H,4H], fw bias [4H], bw kernel,
+ * bw bias) or (kernel, bias); then W [Hin,C], b [C].
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+  int32_t feature_size, hidden, num_layers, bidirectional, merge; /* merge: 0 none, 1 stack_reshape, 2 concat */
+  int32_t num_classes;
+  float forget_bias;
+} cref_spec;
+
+static inline float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+/* C[M,N] = A[M,K] * B[K,N] (+ bias[n]) */
+static void gemm_nn(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    const float* bias) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < M; ++i) {
+    float* c = C + (size_t)i * ldc;
+    for (int j = 0; j < N; ++j) c[j] = bias ? bias[j] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float a = A[(size_t)i * lda + k];
+      if (a == 0.f) continue;
+      const float* b = B + (size_t)k * ldb;
+      for (int j = 0; j < N; ++j) c[j] += a * b[j];
+    }
+  }
+}
+
+/* C[M,N] = A[R,M]^T * B[R,N]   (contraction over rows) */
+static void gemm_tn(const float* A, const float* B, float* C, int M, int N, int R, int lda, int ldb, int ldc) {
+#pragma omp parallel for schedule(static)
+  for (int i0 = 0; i0 < M; i0 += 4) {
+    const int i1 = i0 + 4 < M ? i0 + 4 : M;
+    for (int i = i0; i < i1; ++i) memset(C + (size_t)i * ldc, 0, (size_t)N * sizeof(float));
+    for (int r = 0; r < R; ++r) {
+      const float* b = B + (size_t)r * ldb;
+      for (int i = i0; i < i1; ++i) {
+        const float a = A[(size_t)r * lda + i];
+        if (a == 0.f) continue;
+        float* c = C + (size_t)i * ldc;
+        for (int j = 0; j < N; ++j) c[j] += a * b[j];
+      }
+    }
+  }
+}
+
+/* C[M,N] (+)= A[M,K] * B[N,K]^T */
+static void gemm_nt(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                    int accumulate) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < M; ++i) {
+    const float* a = A + (size_t)i * lda;
+    for (int j = 0; j < N; ++j) {
+      const float* b = B + (size_t)j * ldb;
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s += a[k] * b[k];
+      if (accumulate) C[(size_t)i * ldc + j] += s; else C[(size_t)i * ldc + j] = s;
+    }
+  }
+}
+
+typedef struct {
+  int I, H;
+  const float* kernel; /* [I+H][4H] */
+  const float* bias;
+  float *xp, *act, *c, *out; /* [T*B][4H], [T*B][4H] (si,tj,sf,so), [T*B][H], [T*B][H] */
+} dir_t;
+
+/* one direction of (bidirectional_)dynamic_rnn; X time-major [T*B][I] */
+static void lstm_dir_forward(dir_t* d, const float* X, const int32_t* len, int B, int T, int reverse, float fb) {
+  const int H = d->H, I = d->I, N4 = 4 * H;
+  gemm_nn(X, d->kernel, d->xp, T * B, N4, I, I, N4, N4, d->bias);
+  const float* U = d->kernel + (size_t)I * N4;
+  float* hcur = (float*)calloc((size_t)B * H, sizeof(float));
+  float* hnew = (float*)calloc((size_t)B * H, sizeof(float));
+  float* ccur = (float*)calloc((size_t)B * H, sizeof(float));
+  memset(d->out, 0, (size_t)T * B * H * sizeof(float));
+  memset(d->c, 0, (size_t)T * B * H * sizeof(float));
+  memset(d->act, 0, (size_t)T * B * N4 * sizeof(float));
+#pragma omp parallel
+  for (int s = 0; s < T; ++s) {
+#pragma omp for schedule(static)
+    for (int j0 = 0; j0 < H; j0 += 8) {
+      const int j1 = j0 + 8 < H ? j0 + 8 : H;
+      for (int b = 0; b < B; ++b) {
+        if (s >= len[b]) {
+          for (int j = j0; j < j1; ++j) hnew[(size_t)b * H + j] = hcur[(size_t)b * H + j];
+          continue;
+        }
+        const int tb = reverse ? len[b] - 1 - s : s;
+        const size_t r = (size_t)tb * B + b;
+        float g[4][8];
+        for (int q = 0; q < 4; ++q)
+          for (int j = j0; j < j1; ++j) g[q][j - j0] = d->xp[r * N4 + q * H + j];
+        const float* h = hcur + (size_t)b * H;
+        for (int k = 0; k < H; ++k) {
+          const float hv = h[k];
+          const float* u = U + (size_t)k * N4;
+          for (int q = 0; q < 4; ++q)
+            for (int j = j0; j < j1; ++j) g[q][j - j0] += hv * u[q * H + j];
+        }
+        for (int j = j0; j < j1; ++j) {
+          const float si = sigm(g[0][j - j0]), tj = tanhf(g[1][j - j0]);
+          const float sf = sigm(g[2][j - j0] + fb), so = sigm(g[3][j - j0]);
+          const float cn = ccur[(size_t)b * H + j] * sf + si * tj;
+          const float hn = tanhf(cn) * so;
+          float* a = d->act + r * N4;
+          a[j] = si; a[H + j] = tj; a[2 * H + j] = sf; a[3 * H + j] = so;
+          d->c[r * H + j] = cn;
+          d->out[r * H + j] = hn;
+          ccur[(size_t)b * H + j] = cn;
+          hnew[(size_t)b * H + j] = hn;
+        }
+      }
+    }
+#pragma omp single
+    { float* t = hcur; hcur = hnew; hnew = t; }
+  }
+  free(hcur); free(hnew); free(ccur);
+}
+
+/* BPTT of one direction: dout [T*B][H] -> dG [T*B][4H] (frame indexed, zero at masked frames) */
+static void lstm_dir_backward(const dir_t* d, const float* dout, float* dG, const int32_t* len, int B, int T,
+                              int reverse) {
+  const int H = d->H, I = d->I, N4 = 4 * H;
+  const float* U = d->kernel + (size_t)I * N4;
+  float* dh = (float*)calloc((size_t)B * H, sizeof(float));
+  float* dhn = (float*)calloc((size_t)B * H, sizeof(float));
+  float* dc = (float*)calloc((size_t)B * H, sizeof(float));
+  memset(dG, 0, (size_t)T * B * N4 * sizeof(float));
+#pragma omp parallel
+  for (int s = T - 1; s >= 0; --s) {
+    /* pointwise: dG of this step from dh (recurrent) + dout */
+#pragma omp for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      if (s >= len[b]) continue;
+      const int tb = reverse ? len[b] - 1 - s : s;
+      const size_t r = (size_t)tb * B + b;
+      const size_t rp = reverse ? r + B : r - B;
+      const float* a = d->act + r * N4;
+      float* g = dG + r * N4;
+      for (int j = 0; j < H; ++j) {
+        const float dht = dh[(size_t)b * H + j] + dout[r * H + j];
+        const float si = a[j], tj = a[H + j], sf = a[2 * H + j], so = a[3 * H + j];
+        const float tc = tanhf(d->c[r * H + j]);
+        const float cp = s > 0 ? d->c[rp * H + j] : 0.f;
+        const float dct = dc[(size_t)b * H + j] + dht * so * (1.f - tc * tc);
+        g[j] = dct * tj * si * (1.f - si);
+        g[H + j] = dct * si * (1.f - tj * tj);
+        g[2 * H + j] = dct * cp * sf * (1.f - sf);
+        g[3 * H + j] = dht * tc * so * (1.f - so);
+        dc[(size_t)b * H + j] = dct * sf;
+      }
+    }
+    /* dh_prev[b][k] = sum_n dG[b][n] U[k][n] */
+#pragma omp for schedule(static)
+    for (int k = 0; k < H; ++k) {
+      const float* u = U + (size_t)k * N4;
+      for (int b = 0; b < B; ++b) {
+        if (s >= len[b]) { dhn[(size_t)b * H + k] = dh[(size_t)b * H + k]; continue; }
+        const int tb = reverse ? len[b] - 1 - s : s;
+        const float* g = dG + ((size_t)tb * B + b) * N4;
+        float acc = 0.f;
+        for (int n = 0; n < N4; ++n) acc += g[n] * u[n];
+        dhn[(size_t)b * H + k] = acc;
+      }
+    }
+#pragma omp single
+    { float* t = dh; dh = dhn; dhn = t; }
+  }
+  free(dh); free(dhn); free(dc);
+}
+
+static double lse2(double a, double b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
+}
+
+/* tf.nn.ctc_loss for one utterance; logits rows stride `ls`; grad written in place of a separate buffer */
+static double ctc_one(const float* lg, size_t ls, int Tb, int C, const int32_t* lab, int L, float* grad, float scale) {
+  const int S = 2 * L + 1, blank = C - 1;
+  double* lp = (double*)malloc((size_t)Tb * C * sizeof(double));
+  double* al = (double*)malloc((size_t)Tb * S * sizeof(double));
+  double* be = (double*)malloc((size_t)Tb * S * sizeof(double));
+  for (int t = 0; t < Tb; ++t) {
+    const float* x = lg + (size_t)t * ls;
+    double m = x[0];
+    for (int c = 1; c < C; ++c) if (x[c] > m) m = x[c];
+    double z = 0;
+    for (int c = 0; c < C; ++c) z += exp(x[c] - m);
+    z = m + log(z);
+    for (int c = 0; c < C; ++c) lp[(size_t)t * C + c] = x[c] - z;
+  }
+#define EXT(s) (((s) & 1) ? lab[(s) >> 1] : blank)
+  for (int i = 0; i < Tb * S; ++i) al[i] = be[i] = -INFINITY;
+  al[0] = lp[blank];
+  if (S > 1) al[1] = lp[EXT(1)];
+  for (int t = 1; t < Tb; ++t)
+    for (int s = 0; s < S; ++s) {
+      double v = al[(size_t)(t - 1) * S + s];
+      if (s >= 1) v = lse2(v, al[(size_t)(t - 1) * S + s - 1]);
+      if (s >= 2 && EXT(s) != blank && EXT(s) != EXT(s - 2)) v = lse2(v, al[(size_t)(t - 1) * S + s - 2]);
+      al[(size_t)t * S + s] = v + lp[(size_t)t * C + EXT(s)];
+    }
+  be[(size_t)(Tb - 1) * S + S - 1] = 0;
+  if (S > 1) be[(size_t)(Tb - 1) * S + S - 2] = 0;
+  for (int t = Tb - 2; t >= 0; --t)
+    for (int s = 0; s < S; ++s) {
+      double v = be[(size_t)(t + 1) * S + s] + lp[(size_t)(t + 1) * C + EXT(s)];
+      if (s + 1 < S) v = lse2(v, be[(size_t)(t + 1) * S + s + 1] + lp[(size_t)(t + 1) * C + EXT(s + 1)]);
+      if (s + 2 < S && EXT(s + 2) != blank && EXT(s + 2) != EXT(s))
+        v = lse2(v, be[(size_t)(t + 1) * S + s + 2] + lp[(size_t)(t + 1) * C + EXT(s + 2)]);
+      be[(size_t)t * S + s] = v;
+    }
+  double logp = -INFINITY;
+  for (int s = 0; s < S; ++s) logp = lse2(logp, al[s] + be[s]);
+  double* post = (double*)malloc((size_t)C * sizeof(double));
+  for (int t = 0; t < Tb; ++t) {
+    for (int c = 0; c < C; ++c) post[c] = 0;
+    for (int s = 0; s < S; ++s) post[EXT(s)] += exp(al[(size_t)t * S + s] + be[(size_t)t * S + s] - logp);
+    for (int c = 0; c < C; ++c) grad[(size_t)t * ls + c] = (float)((exp(lp[(size_t)t * C + c]) - post[c]) * scale);
+  }
+#undef EXT
+  free(post); free(lp); free(al); free(be);
+  return -logp;
+}
+
+int64_t cref_param_count(const cref_spec* sp) {
+  const int D = sp->bidirectional ? 2 : 1, H = sp->hidden;
+  int64_t n = 0;
+  for (int l = 0; l < sp->num_layers; ++l) {
+    const int I = l == 0 ? sp->feature_size : D * H;
+    n += (int64_t)D * ((int64_t)(I + H) * 4 * H + 4 * H);
+  }
+  const int Pin = (sp->bidirectional && sp->merge == 2) ? 2 * H : H;
+  return n + (int64_t)Pin * sp->num_classes + sp->num_classes;
+}
+
+int cref_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* loss = mean CTC nll and d loss / d params (TF order).  feats [B,T,F] batch-major.  Returns 0, or -3 when a label
+ * needs more frames than seq_len ("Not enough time for target transition sequence"). grads/logits may be NULL. */
+int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* feats, const int32_t* seq_len,
+                        const int32_t* labels, const int32_t* label_len, int B, int T, int Lmax, float* loss_out,
+                        float* nll_out, float* grads, float* logits_out) {
+  const int D = sp->bidirectional ? 2 : 1, H = sp->hidden, C = sp->num_classes, L = sp->num_layers, F = sp->feature_size;
+  const int sr = sp->bidirectional && sp->merge == 1;
+  const int Pin = (sp->bidirectional && sp->merge == 2) ? 2 * H : H;
+  const int Tp = sr ? 2 * T : T;
+  const size_t R = (size_t)T * B;
+  for (int b = 0; b < B; ++b) {
+    int rep = 0;
+    for (int i = 1; i < label_len[b]; ++i) rep += labels[(size_t)b * Lmax + i] == labels[(size_t)b * Lmax + i - 1];
+    if (label_len[b] + rep > seq_len[b]) return -3;
+  }
+  /* ---- parameter views */
+  dir_t* dirs = (dir_t*)calloc((size_t)L * D, sizeof(dir_t));
+  const float* p = params;
+  for (int l = 0; l < L; ++l)
+    for (int d = 0; d < D; ++d) {
+      dir_t* q = &dirs[l * D + d];
+      q->I = l == 0 ? F : D * H; q->H = H;
+      q->kernel = p; p += (size_t)(q->I + H) * 4 * H;
+      q->bias = p; p += 4 * H;
+      q->xp = (float*)malloc(R * 4 * H * sizeof(float));
+      q->act = (float*)malloc(R * 4 * H * sizeof(float));
+      q->c = (float*)malloc(R * H * sizeof(float));
+      q->out = (float*)malloc(R * H * sizeof(float));
+    }
+  const float* W = p; p += (size_t)Pin * C;
+  const float* bproj = p;
+  /* ---- forward */
+  float** X = (float**)calloc((size_t)L + 1, sizeof(float*));
+  X[0] = (float*)malloc(R * F * sizeof(float));
+#pragma omp parallel for
+  for (int t = 0; t < T; ++t)
+    for (int b = 0; b < B; ++b) memcpy(X[0] + ((size_t)t * B + b) * F, feats + ((size_t)b * T + t) * F, (size_t)F * sizeof(float));
+  for (int l = 0; l < L; ++l) {
+    for (int d = 0; d < D; ++d) lstm_dir_forward(&dirs[l * D + d], X[l], seq_len, B, T, d == 1, sp->forget_bias);
+    X[l + 1] = (float*)malloc(R * D * H * sizeof(float));
+#pragma omp parallel for
+    for (size_t r = 0; r < R; ++r)
+      for (int d = 0; d < D; ++d) memcpy(X[l + 1] + (r * D + d) * H, dirs[l * D + d].out + r * H, (size_t)H * sizeof(float));
+  }
+  /* projection input rows: flat[q] for logits row (t', b') */
+  const size_t Rp = (size_t)Tp * B;
+  float* flat = (float*)malloc(Rp * Pin * sizeof(float));
+#pragma omp parallel for
+  for (size_t rr = 0; rr < Rp; ++rr) {
+    const int tp = (int)(rr / B), bq = (int)(rr % B);
+    if (sr) { /* row b'*2T + t' of stack(fw,bw) [2,B,T,H] */
+      const int64_t qq = (int64_t)bq * 2 * T + tp;
+      const int d = (int)(qq / ((int64_t)B * T));
+      const int64_t rem = qq % ((int64_t)B * T);
+      const int b = (int)(rem / T), t = (int)(rem % T);
+      memcpy(flat + rr * Pin, dirs[(L - 1) * D + d].out + ((size_t)t * B + b) * H, (size_t)H * sizeof(float));
+    } else {
+      memcpy(flat + rr * Pin, X[L] + rr * Pin, (size_t)Pin * sizeof(float));
+    }
+  }
+  float* logits = (float*)malloc(Rp * C * sizeof(float));
+  gemm_nn(flat, W, logits, (int)Rp, C, Pin, Pin, C, C, bproj);
+  if (logits_out) memcpy(logits_out, logits, Rp * C * sizeof(float));
+  /* ---- CTC */
+  float* dlog = (float*)calloc(Rp * C, sizeof(float));
+  double total = 0;
+  double* nlls = (double*)malloc((size_t)B * sizeof(double));
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < B; ++b)
+    nlls[b] = ctc_one(logits + (size_t)b * C, (size_t)B * C, seq_len[b], C, labels + (size_t)b * Lmax, label_len[b],
+                      dlog + (size_t)b * C, 1.f / (float)B);
+  for (int b = 0; b < B; ++b) { total += nlls[b]; if (nll_out) nll_out[b] = (float)nlls[b]; }
+  if (loss_out) *loss_out = (float)(total / B);
+  if (grads) {
+    float* g = grads;
+    float** gk = (float**)calloc((size_t)L * D, sizeof(float*));
+    float** gb = (float**)calloc((size_t)L * D, sizeof(float*));
+    for (int l = 0; l < L; ++l)
+      for (int d = 0; d < D; ++d) {
+        gk[l * D + d] = g; g += (size_t)(dirs[l * D + d].I + H) * 4 * H;
+        gb[l * D + d] = g; g += 4 * H;
+      }
+    float* gW = g; g += (size_t)Pin * C;
+    float* gbp = g;
+    gemm_tn(flat, dlog, gW, Pin, C, (int)Rp, Pin, C, C);
+    for (int c = 0; c < C; ++c) { double s = 0; for (size_t rr = 0; rr < Rp; ++rr) s += dlog[rr * C + c]; gbp[c] = (float)s; }
+    float* dflat = (float*)malloc(Rp * Pin * sizeof(float));
+    gemm_nt(dlog, W, dflat, (int)Rp, Pin, C, C, C, Pin, 0);
+    /* gradient wrt the last layer's outputs, per direction [T*B][H] */
+    float** dout = (float**)calloc((size_t)D, sizeof(float*));
+    for (int d = 0; d < D; ++d) dout[d] = (float*)calloc(R * H, sizeof(float));
+#pragma omp parallel for
+    for (size_t rr = 0; rr < Rp; ++rr) {
+      const int tp = (int)(rr / B), bq = (int)(rr % B);
+      if (sr) {
+        const int64_t qq = (int64_t)bq * 2 * T + tp;
+        const int d = (int)(qq / ((int64_t)B * T));
+        const int64_t rem = qq % ((int64_t)B * T);
+        const int b = (int)(rem / T), t = (int)(rem % T);
+        memcpy(dout[d] + ((size_t)t * B + b) * H, dflat + rr * Pin, (size_t)H * sizeof(float));
+      } else {
+        for (int d = 0; d < D; ++d) memcpy(dout[d] + rr * H, dflat + rr * Pin + (size_t)d * H, (size_t)H * sizeof(float));
+      }
+    }
+    float* dG = (float*)malloc(R * 4 * H * sizeof(float));
+    float* hprev = (float*)malloc(R * H * sizeof(float));
+    for (int l = L - 1; l >= 0; --l) {
+      const int I = dirs[l * D].I;
+      float* dX = l > 0 ? (float*)calloc(R * I, sizeof(float)) : NULL;
+      for (int d = 0; d < D; ++d) {
+        dir_t* q = &dirs[l * D + d];
+        lstm_dir_backward(q, dout[d], dG, seq_len, B, T, d == 1);
+        gemm_tn(X[l], dG, gk[l * D + d], I, 4 * H, (int)R, I, 4 * H, 4 * H);
+        /* h_prev of frame t: out[t-1] (fw) / out[t+1] (bw), zero at the ends */
+        memset(hprev, 0, R * H * sizeof(float));
+        if (d == 0) memcpy(hprev + (size_t)B * H, q->out, (R - B) * H * sizeof(float));
+        else memcpy(hprev, q->out + (size_t)B * H, (R - B) * H * sizeof(float));
+        gemm_tn(hprev, dG, gk[l * D + d] + (size_t)I * 4 * H, H, 4 * H, (int)R, H, 4 * H, 4 * H);
+        for (int n = 0; n < 4 * H; ++n) { double s = 0; for (size_t r = 0; r < R; ++r) s += dG[r * 4 * H + n]; gb[l * D + d][n] = (float)s; }
+        if (l > 0) gemm_nt(dG, q->kernel, dX, (int)R, I, 4 * H, 4 * H, 4 * H, I, 1);   /* rows 0..I-1 of kernel = Wx */
+      }
+      if (l > 0) {
+        for (int d = 0; d < D; ++d)
+#pragma omp parallel for
+          for (size_t r = 0; r < R; ++r) memcpy(dout[d] + r * H, dX + r * I + (size_t)d * H, (size_t)H * sizeof(float));
+        free(dX);
+      }
+    }
+    free(dG); free(hprev); free(dflat);
+    for (int d = 0; d < D; ++d) free(dout[d]);
+    free(dout); free(gk); free(gb);
+  }
+  free(nlls); free(dlog); free(logits); free(flat);
+  for (int l = 0; l <= L; ++l) free(X[l]);
+  free(X);
+  for (int i = 0; i < L * D; ++i) { free(dirs[i].xp); free(dirs[i].act); free(dirs[i].c); free(dirs[i].out); }
+  free(dirs);
+  return 0;
+}
