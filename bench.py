@@ -83,9 +83,13 @@ def cpu_baseline(spec, B, seed):
         dt, fr = run(24)
         Tc = int(max(32, min(500, 24 * 14.0 / max(dt, 1e-3))))
         dt, fr = run(Tc)
+        reps = 1
+        while dt < 10.0 and reps < 8:                  # a fast host: repeat the step until ~10 s are on the clock
+            d2, f2 = run(Tc)
+            dt, fr, reps = dt + d2, fr + f2, reps + 1
         return {'value': fr / dt, 'unit': 'frames/s', 'cores': int(threads), 'kind': 'port',
-                'sample': f'oracle/cref/nasr_cref.c (C + OpenMP, fp32), 1 fwd+CTC+bwd step of the same net at B={B}, '
-                          f'T={Tc} ({fr} frames, {dt:.1f} s); Adam excluded'}
+                'sample': f'oracle/cref/nasr_cref.c (C + OpenMP, fp32), {reps} fwd+CTC+bwd step(s) of the same net at '
+                          f'B={B}, T={Tc} ({fr} frames, {dt:.1f} s); Adam excluded'}
     except Exception as exc:                           # noqa: BLE001 - baseline must not take the bench down
         note = f'C restatement unavailable ({type(exc).__name__}); '
     try:
