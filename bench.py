@@ -71,6 +71,7 @@ def cpu_baseline(spec, B, seed):
     from oracle import nasr_oracle as O
     try:
         from oracle import cref
+        cref.set_threads(cref.usable_cpus())           # honour the container's CPU quota
         threads = cref.num_threads()
         params = O.flatten(O.init_params(spec, seed=1)).astype(np.float32)
 

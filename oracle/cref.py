@@ -28,11 +28,29 @@ def load():
         lib.cref_param_count.restype = ctypes.c_int64
         lib.cref_param_count.argtypes = [ctypes.POINTER(Spec)]
         lib.cref_num_threads.restype = ctypes.c_int
+        lib.cref_set_threads.argtypes = [ctypes.c_int]
         lib.cref_loss_and_grads.restype = ctypes.c_int
         lib.cref_loss_and_grads.argtypes = [ctypes.POINTER(Spec), fp, fp, ip, ip, ip, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, fp, fp, fp, fp]
         _lib = lib
     return _lib
+
+
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (a container with a
+    16-CPU quota on a 256-thread host must not run 256 OpenMP threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def set_threads(n):
+    load().cref_set_threads(int(n))
 
 
 def num_threads():

@@ -258,6 +258,14 @@ int64_t cref_param_count(const cref_spec* sp) {
   return n + (int64_t)Pin * sp->num_classes + sp->num_classes;
 }
 
+void cref_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int cref_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
