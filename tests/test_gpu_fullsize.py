@@ -91,3 +91,26 @@ def test_time_sliced_towers_equal_one_tower_for_concat():
     assert np.mean(ls) == pytest.approx(lg, rel=1e-6)
     assert rel(acc / 2, gg) < 1e-5
     e.close()
+
+
+def test_headline_3x500_full_size_matches_c_restatement():
+    """BASELINE.json configs[1] (3x500 bidirectional, concat) at B = 16, T = 500 against oracle/cref (fp32 C,
+    itself pinned against the fp64 oracle in tests/test_cref.py); the fp64 oracle would need minutes here."""
+    from oracle import cref
+    cref.set_threads(cref.usable_cpus())
+    spec = O.ModelSpec(546, 500, 3, True, 'concat', 29)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 16, 500, seed=77, var_len=True)
+    p = O.flatten(O.init_params(spec, seed=1)).astype(np.float32)
+    e = engine_for(spec)
+    e.set_params(p)
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    lo, nllo, go, _ = cref.loss_and_grads(spec, p, feats, seq_len, labels, label_len)
+    assert loss == pytest.approx(lo, rel=1e-4)
+    np.testing.assert_allclose(nll, nllo, rtol=1e-4)
+    off = 0
+    for (name, shp) in spec.param_shapes():
+        n = int(np.prod(shp))
+        assert rel(grads[off:off + n], go[off:off + n]) < 3e-4, name
+        off += n
+    assert rel(grads, go) < 1e-4
+    e.close()
