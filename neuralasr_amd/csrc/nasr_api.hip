@@ -56,12 +56,15 @@ struct TensorInfo {
 
 enum Phase { PH_PACK = 0, PH_XPROJ, PH_RECF, PH_PROJCTC, PH_PROJB, PH_RECB, PH_WGRAD, PH_ADAM, PH_COUNT };
 
+constexpr int PIPE_MAX_CHUNKS = 16;
+
 struct GraphKey {
-  int T, l, bwd;
+  int T, l, bwd, s0;
   bool operator<(const GraphKey& o) const {
     if (T != o.T) return T < o.T;
     if (l != o.l) return l < o.l;
-    return bwd < o.bwd;
+    if (bwd != o.bwd) return bwd < o.bwd;
+    return s0 < o.s0;
   }
 };
 
@@ -72,10 +75,14 @@ struct nasr_ctx {
   int device = 0;
   hipStream_t st = nullptr;
   bool own_stream = false;
-  hipStream_t side = nullptr;          // low-priority stream: weight-gradient GEMMs of layer l under BPTT of layer l-1
-  bool overlap = true;
+  // Unidirectional stacks (LstmCTCNet): layer l works on time chunk c while layer l+1 works on chunk c-1, each
+  // layer on its own stream (a uni-directional step launch fills only half the CUs).
+  bool pipe = false;
+  int pipe_chunks = 1;                 // chunks of the resident batch (1 = not pipelined)
+  std::vector<hipStream_t> lst;        // per-layer streams, lst[0] == st
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_done, ev_dx;   // [layer * PIPE_MAX_CHUNKS + chunk]
   bool gemm_bf16 = true;               // bulk GEMMs on the bf16 matrix cores (fp32-accurate 3-way split), NASR_GEMM=f32 disables
-  std::vector<hipEvent_t> ev_bptt, ev_wgrad;
   std::string err;
 
   // model dims
@@ -100,9 +107,10 @@ struct nasr_ctx {
   int64_t frames = 0;
   std::vector<int32_t> h_seq;
 
-  DevBuf X0T, outT0, outT1, dGT, feats_bm, X0, dout, hstate, partial, dcstate, dgbuf, dgbuf2, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
+  DevBuf X0T, outT0, outT1, dGT, feats_bm, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
       rowmap, slabs, csws, amax, ids, lens, stage;
   std::vector<DevBuf> gates, outb, cbuf;
+  std::vector<DevBuf> doutL, hstateL, partialL, dcstateL, dgL;   // one each, or one per layer when pipelined
 
   // graphs
   bool graph_mode = true;
@@ -311,18 +319,19 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   bool ok = true;
   ok &= h->feats_bm.ensure((size_t)B * T * h->F * 4, &grew);
   ok &= h->X0.ensure(R * h->Fp * 4, &grew);
-  ok &= h->dout.ensure(R * D * Hp * 4, &grew);
-  ok &= h->hstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
-  ok &= h->partial.ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
-  ok &= h->dcstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
-  ok &= h->dgbuf.ensure(R * D * N4 * 4, &grew);
+  for (size_t i = 0; i < h->doutL.size(); ++i) {
+    ok &= h->doutL[i].ensure(R * D * Hp * 4, &grew);
+    ok &= h->hstateL[i].ensure((size_t)2 * D * Bp * Hp * 4, &grew);
+    ok &= h->partialL[i].ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
+    ok &= h->dcstateL[i].ensure((size_t)2 * D * Bp * Hp * 4, &grew);
+    ok &= h->dgL[i].ensure(R * D * N4 * 4, &grew);
+  }
   if (h->gemm_bf16) {
     ok &= h->X0T.ensure(R * h->Fp * 4, &grew);
     ok &= h->outT0.ensure(R * D * Hp * 4, &grew);
     ok &= h->outT1.ensure(R * D * Hp * 4, &grew);
     ok &= h->dGT.ensure(R * D * N4 * 4, &grew);
   }
-  if (h->L > 1 && h->overlap) ok &= h->dgbuf2.ensure(R * D * N4 * 4, &grew);
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
   const int KSa = KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations
@@ -348,6 +357,8 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   }
   if (!ok) return h->fail(NASR_ERR_HIP, "hipMalloc failed while sizing batch buffers");
   if (grew || Bp != h->Bp) drop_graphs(h);
+  // pipeline the layers of a unidirectional stack over time chunks of >= 32 frames
+  h->pipe_chunks = h->pipe ? std::max(1, std::min(PIPE_MAX_CHUNKS, std::min(10, T / 32))) : 1;
   h->B = B; h->Bp = Bp; h->T = T; h->Lmax = Lmax; h->Tp = Tp; h->KS = KSa;
   return NASR_OK;
 }
@@ -452,36 +463,39 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
   return NASR_OK;
 }
 
-// dG of layer l: two buffers alternate so layer l's weight-gradient GEMMs (side stream) can still read theirs
-// while BPTT of layer l-1 writes the other
-float* dg_of(nasr_ctx* h, int l) {
-  return (h->L > 1 && h->overlap && (l & 1)) ? h->dgbuf2.as<float>() : h->dgbuf.as<float>();
-}
+// per-layer state: one shared set, or one set per layer when the layers are pipelined
+inline size_t lidx(const nasr_ctx* h, int l) { return h->doutL.size() > 1 ? (size_t)l : 0; }
+inline float* dout_of(nasr_ctx* h, int l) { return h->doutL[lidx(h, l)].as<float>(); }
+inline float* dg_of(nasr_ctx* h, int l) { return h->dgL[lidx(h, l)].as<float>(); }
+inline hipStream_t stream_of(nasr_ctx* h, int l) { return (h->pipe_chunks > 1 && l > 0) ? h->lst[l] : h->st; }
 
-// ---- the per-timestep loops, optionally replayed from a hipGraph ---------------------------
-int run_steps(nasr_ctx* h, int l, bool bwd) {
+// ---- the per-timestep loops over steps [s0, s1), optionally replayed from a hipGraph -----------
+int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
   const LstmDims dm{h->T, h->B, h->Bp, h->H, h->Hp, h->D};
   const size_t sU = (size_t)l * h->D * h->Hp * h->N4;
   const size_t hs = (size_t)h->D * h->Bp * h->Hp;   // one h-state image
   const size_t ps = (size_t)h->D * (h->Hp / 32) * h->Bp * h->Hp;   // one partial-sum image
+  float* hst = h->hstateL[lidx(h, l)].as<float>();
+  float* par = h->partialL[lidx(h, l)].as<float>();
+  float* dcs = h->dcstateL[lidx(h, l)].as<float>();
   auto body = [&]() {
     if (!bwd) {
-      (void)hipMemsetAsync(h->hstate.p, 0, hs * 4, h->st);
-      for (int s = 0; s < h->T; ++s)
-        launch_lstm_fwd_step(dm, s, h->Uf + sU, h->hstate.as<float>() + (s & 1) * hs,
-                             h->hstate.as<float>() + ((s + 1) & 1) * hs, h->gates[l].as<float>(),
-                             h->cbuf[l].as<float>(), h->outb[l].as<float>(), h->seq.as<int>(), h->cfg.forget_bias,
-                             h->st);
+      if (s0 == 0) (void)hipMemsetAsync(hst, 0, hs * 4, st);
+      for (int s = s0; s < s1; ++s)
+        launch_lstm_fwd_step(dm, s, h->Uf + sU, hst + (s & 1) * hs, hst + ((s + 1) & 1) * hs,
+                             h->gates[l].as<float>(), h->cbuf[l].as<float>(), h->outb[l].as<float>(),
+                             h->seq.as<int>(), h->cfg.forget_bias, st);
     } else {
-      (void)hipMemsetAsync(h->partial.p, 0, ps * 4, h->st);
-      (void)hipMemsetAsync(h->dcstate.p, 0, hs * 4, h->st);
-      int k = 0;
-      for (int s = h->T - 1; s >= 0; --s, ++k)
-        launch_lstm_bwd_step(dm, s, h->Ub + sU, h->partial.as<float>() + (k & 1) * ps,
-                             h->partial.as<float>() + ((k + 1) & 1) * ps, h->gates[l].as<float>(),
-                             dg_of(h, l), h->cbuf[l].as<float>(), h->dout.as<float>(),
-                             h->dcstate.as<float>() + (k & 1) * hs, h->dcstate.as<float>() + ((k + 1) & 1) * hs,
-                             h->seq.as<int>(), h->st);
+      if (s1 == h->T) {
+        (void)hipMemsetAsync(par, 0, ps * 4, st);
+        (void)hipMemsetAsync(dcs, 0, hs * 4, st);
+      }
+      for (int s = s1 - 1; s >= s0; --s) {
+        const int k = h->T - 1 - s;
+        launch_lstm_bwd_step(dm, s, h->Ub + sU, par + (k & 1) * ps, par + ((k + 1) & 1) * ps,
+                             h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(), dout_of(h, l),
+                             dcs + (k & 1) * hs, dcs + ((k + 1) & 1) * hs, h->seq.as<int>(), st);
+      }
     }
   };
   if (!h->graph_mode) {
@@ -489,20 +503,20 @@ int run_steps(nasr_ctx* h, int l, bool bwd) {
     HIPCHK(h, hipGetLastError());
     return NASR_OK;
   }
-  const GraphKey key{h->T, l, bwd ? 1 : 0};
+  const GraphKey key{h->T, l, bwd ? 1 : 0, s0 * 4096 + (s1 - s0)};
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
-    if (h->graphs.size() > 48) drop_graphs(h);
+    if (h->graphs.size() > 256) drop_graphs(h);
     hipGraph_t g = nullptr;
-    HIPCHK(h, hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal));
+    HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     body();
-    HIPCHK(h, hipStreamEndCapture(h->st, &g));
+    HIPCHK(h, hipStreamEndCapture(st, &g));
     hipGraphExec_t ex = nullptr;
     HIPCHK(h, hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
     it = h->graphs.emplace(key, ex).first;
   }
-  HIPCHK(h, hipGraphLaunch(it->second, h->st));
+  HIPCHK(h, hipGraphLaunch(it->second, st));
   return NASR_OK;
 }
 
@@ -513,40 +527,91 @@ float* ensure_slabs(nasr_ctx* h, int split, int M, int N) {
   return h->slabs.as<float>();
 }
 
+// gates_l[r0 .. r0+nr) = X_l[r0 ..] * Wx_l + bias_l   (rows are time-major, so a time chunk is a row range)
+void gemm_xproj(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
+  const int D = h->D, N4 = h->N4, Ip = h->Ip[l];
+  const float* Xl = (l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>()) + (size_t)r0 * Ip;
+  float* C = h->gates[l].as<float>() + (size_t)r0 * D * N4;
+  if (h->gemm_bf16) {
+    GemmNTDesc g{};
+    g.A = Xl; g.B = h->WxT + h->off_wxt[l]; g.C = C;
+    g.M = nr; g.N = D * N4; g.K = Ip; g.lda = Ip; g.ldb = Ip; g.ldc = D * N4;
+    g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+    launch_gemm_nt(g, st);
+  } else {
+    GemmDesc g{};
+    g.A = Xl; g.B = h->P + h->off_wx[l]; g.C = C;
+    g.M = nr; g.N = D * N4; g.K = Ip; g.lda = Ip; g.ldb = D * N4; g.ldc = D * N4;
+    g.a_rows = nr; g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+    launch_gemm(g, st);
+  }
+}
+
+// dOut_{l-1}[r0 ..) = dG_l[r0 ..) * Wx_l^T : the gradient wrt layer l's input = the layer below's output
+void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
+  const int D = h->D, N4 = h->N4, Hp = h->Hp;
+  const float* A = dg_of(h, l) + (size_t)r0 * D * N4;
+  float* C = dout_of(h, l - 1) + (size_t)r0 * D * Hp;
+  if (h->gemm_bf16) {
+    GemmNTDesc g{};
+    g.A = A; g.B = h->P + h->off_wx[l]; g.C = C;
+    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp; g.split_k = 1;
+    launch_gemm_nt(g, st);
+  } else {
+    GemmDesc g{};
+    g.A = A; g.B = h->P + h->off_wx[l]; g.C = C;
+    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp;
+    g.b_col = true; g.a_rows = nr; g.split_k = 1;
+    launch_gemm(g, st);
+  }
+}
+
+int pipe_fork(nasr_ctx* h) {
+  HIPCHK(h, hipEventRecord(h->ev_fork, h->st));
+  for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->lst[l], h->ev_fork, 0));
+  return NASR_OK;
+}
+
 int forward(nasr_ctx* h) {
   if (!h->resident) return h->fail(NASR_ERR_STATE, "no resident batch: call nasr_upload_batch first");
-  const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp, N4 = h->N4;
+  const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp;
   const int R = T * Bp;
   h->n_fwd_launch = 0;
-  for (int l = 0; l < h->L; ++l) {
-    {
-      PhaseScope ps(h, PH_XPROJ);
-      const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
-      if (h->gemm_bf16) {
-        GemmNTDesc g{};
-        g.A = Xl; g.B = h->WxT + h->off_wxt[l]; g.C = h->gates[l].as<float>();
-        g.M = R; g.N = D * N4; g.K = h->Ip[l];
-        g.lda = h->Ip[l]; g.ldb = h->Ip[l]; g.ldc = D * N4;
-        g.bias = h->P + h->off_bias[l]; g.split_k = 1;
-        launch_gemm_nt(g, h->st);
-      } else {
-        GemmDesc g{};
-        g.A = Xl;
-        g.B = h->P + h->off_wx[l];
-        g.C = h->gates[l].as<float>();
-        g.M = R; g.N = D * N4; g.K = h->Ip[l];
-        g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
-        g.a_col = false; g.b_col = false; g.a_rows = R; g.bias = h->P + h->off_bias[l]; g.split_k = 1;
-        launch_gemm(g, h->st);
+  const int NC = h->pipe_chunks;
+  if (NC <= 1) {
+    for (int l = 0; l < h->L; ++l) {
+      {
+        PhaseScope ps(h, PH_XPROJ);
+        gemm_xproj(h, l, 0, R, h->st);
+        HIPCHK(h, hipGetLastError());
       }
-      HIPCHK(h, hipGetLastError());
-    }
-    {
       PhaseScope ps(h, PH_RECF);
-      int rc = run_steps(h, l, false);
+      int rc = run_steps(h, l, false, 0, T, h->st);
       if (rc) return rc;
       h->n_fwd_launch += T;
     }
+  } else {
+    // layer l, chunk c needs layer l-1's chunk c and its own chunk c-1 (same stream)
+    PhaseScope ps(h, PH_RECF);
+    const int Tc = (T + NC - 1) / NC;
+    int rc = pipe_fork(h);
+    if (rc) return rc;
+    for (int c = 0; c < NC; ++c) {
+      const int t0 = c * Tc, t1 = std::min(T, t0 + Tc);
+      if (t0 >= t1) break;
+      for (int l = 0; l < h->L; ++l) {
+        hipStream_t st = stream_of(h, l);
+        if (l > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_done[(l - 1) * PIPE_MAX_CHUNKS + c], 0));
+        gemm_xproj(h, l, t0 * Bp, (t1 - t0) * Bp, st);
+        rc = run_steps(h, l, false, t0, t1, st);
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_done[l * PIPE_MAX_CHUNKS + c], st));
+      }
+    }
+    const int lastc = (T - 1) / Tc;
+    for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_done[l * PIPE_MAX_CHUNKS + lastc], 0));
+    h->n_fwd_launch = T + (h->L - 1) * Tc;   // length of the critical path in step launches
+    HIPCHK(h, hipGetLastError());
   }
   {
     PhaseScope ps(h, PH_PROJCTC);
@@ -591,8 +656,77 @@ int ctc_forward(nasr_ctx* h) {
   return NASR_OK;
 }
 
-int backward(nasr_ctx* h) {
+// weight / bias gradients of layer l from its complete dG (on the main stream)
+int weight_grads(nasr_ctx* h, int l) {
   const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp, N4 = h->N4;
+  const int R = T * Bp;
+  float* dG = dg_of(h, l);
+  hipStream_t ws = h->st;
+  const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
+  if (h->gemm_bf16) {
+    // K-contiguous copies of the operands whose contraction index is the row (time) index
+    float* tOut[2] = {h->outT0.as<float>(), h->outT1.as<float>()};
+    launch_transpose(dG, h->dGT.as<float>(), R, D * N4, D * N4, R, ws);
+    if (l == h->L - 1) launch_transpose(h->outb[l].as<float>(), tOut[l & 1], R, D * Hp, D * Hp, R, ws);
+    if (l > 0) launch_transpose(h->outb[l - 1].as<float>(), tOut[(l - 1) & 1], R, D * Hp, D * Hp, R, ws);
+    const float* XT = l == 0 ? h->X0T.as<float>() : tOut[(l - 1) & 1];
+    {  // dWx = X^T dG
+      GemmNTDesc g{};
+      g.A = XT; g.B = h->dGT.as<float>(); g.C = h->G + h->off_wx[l];
+      g.M = h->Ip[l]; g.N = D * N4; g.K = R;
+      g.lda = R; g.ldb = R; g.ldc = D * N4;
+      g.split_k = gemm_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm_nt(g, ws);
+    }
+    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
+    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
+      GemmNTDesc g{};
+      g.A = tOut[l & 1] + (size_t)d * Hp * R;
+      g.B = h->dGT.as<float>() + (size_t)d * N4 * R;
+      g.C = h->G + h->off_u[(size_t)l * D + d];
+      g.M = Hp; g.N = N4; g.K = R;
+      g.lda = R; g.ldb = R; g.ldc = N4;
+      g.a_kshift = d == 0 ? -Bp : Bp;
+      g.split_k = gemm_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm_nt(g, ws);
+    }
+  } else {
+    {  // dWx = X^T dG
+      GemmDesc g{};
+      g.A = Xl; g.B = dG; g.C = h->G + h->off_wx[l];
+      g.M = h->Ip[l]; g.N = D * N4; g.K = R;
+      g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
+      g.a_col = true; g.a_rows = R;
+      g.split_k = gemm_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm(g, ws);
+    }
+    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
+    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
+      GemmDesc g{};
+      g.A = h->outb[l].as<float>() + d * Hp;
+      g.B = dG + d * N4;
+      g.C = h->G + h->off_u[(size_t)l * D + d];
+      g.M = Hp; g.N = N4; g.K = R;
+      g.lda = D * Hp; g.ldb = D * N4; g.ldc = N4;
+      g.a_col = true; g.a_shift = d == 0 ? -Bp : Bp; g.a_rows = R;
+      g.split_k = gemm_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm(g, ws);
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  return NASR_OK;
+}
+
+int backward(nasr_ctx* h) {
+  const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp;
   const int R = T * Bp, Rp = h->Tp * Bp;
   const bool sr = h->cfg.merge == NASR_MERGE_STACK_RESHAPE && D == 2;
   {
@@ -622,7 +756,7 @@ int backward(nasr_ctx* h) {
     GemmDesc x{};
     x.A = h->logits.as<float>();
     x.B = h->P + h->off_w;
-    x.C = h->dout.as<float>();
+    x.C = dout_of(h, h->L - 1);
     x.M = Rp; x.N = h->Pinp; x.K = h->Cp;
     x.lda = h->Cp; x.ldb = h->Cp; x.ldc = sr ? Hp : D * Hp;
     x.b_col = true; x.a_rows = Rp; x.c_map = sr ? h->rowmap.as<int>() : nullptr; x.split_k = 1;
@@ -630,103 +764,49 @@ int backward(nasr_ctx* h) {
     HIPCHK(h, hipGetLastError());
   }
   h->n_bwd_launch = 0;
-  const bool ov = h->overlap && h->L > 1 && h->side;
-  for (int l = h->L - 1; l >= 0; --l) {
-    float* dG = dg_of(h, l);
-    // layer l+2 used this dG buffer: its weight-gradient GEMMs must have read it before BPTT overwrites it
-    if (ov && l + 2 < h->L) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_wgrad[l + 2], 0));
+  const int NC = h->pipe_chunks;
+  if (NC <= 1) {
+    for (int l = h->L - 1; l >= 0; --l) {
+      {
+        PhaseScope ps(h, PH_RECB);
+        int rc = run_steps(h, l, true, 0, T, h->st);
+        if (rc) return rc;
+        h->n_bwd_launch += T;
+      }
+      PhaseScope ps(h, PH_WGRAD);
+      if (l > 0) gemm_dx(h, l, 0, R, h->st);   // critical path first
+      int rc = weight_grads(h, l);
+      if (rc) return rc;
+    }
+  } else {
+    // BPTT of layer l on chunk c needs dOut_l[chunk c] = dX GEMM of layer l+1's chunk c, and its own chunk c+1
     {
       PhaseScope ps(h, PH_RECB);
-      int rc = run_steps(h, l, true);
+      const int Tc = (T + NC - 1) / NC;
+      int rc = pipe_fork(h);
       if (rc) return rc;
-      h->n_bwd_launch += T;
+      const int lastc = (T - 1) / Tc;
+      for (int c = lastc; c >= 0; --c) {
+        const int t0 = c * Tc, t1 = std::min(T, t0 + Tc);
+        for (int l = h->L - 1; l >= 0; --l) {
+          hipStream_t st = stream_of(h, l);
+          if (l < h->L - 1) HIPCHK(h, hipStreamWaitEvent(st, h->ev_dx[(l + 1) * PIPE_MAX_CHUNKS + c], 0));
+          rc = run_steps(h, l, true, t0, t1, st);
+          if (rc) return rc;
+          if (l > 0) gemm_dx(h, l, t0 * Bp, (t1 - t0) * Bp, st);
+          HIPCHK(h, hipEventRecord(h->ev_dx[l * PIPE_MAX_CHUNKS + c], st));
+        }
+      }
+      for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_dx[l * PIPE_MAX_CHUNKS + 0], 0));
+      h->n_bwd_launch = T + (h->L - 1) * Tc;
+      HIPCHK(h, hipGetLastError());
     }
     PhaseScope ps(h, PH_WGRAD);
-    hipStream_t ws = h->st;
-    if (ov && l > 0) {   // the last layer processed (l = 0) has nothing left to hide under
-      HIPCHK(h, hipEventRecord(h->ev_bptt[l], h->st));
-      HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_bptt[l], 0));
-      ws = h->side;
+    for (int l = h->L - 1; l >= 0; --l) {
+      int rc = weight_grads(h, l);
+      if (rc) return rc;
     }
-    const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
-    if (h->gemm_bf16) {
-      if (l > 0) {  // critical path first: dOut_{l-1} = dG * Wx^T (both operands K-contiguous as stored)
-        GemmNTDesc g{};
-        g.A = dG; g.B = h->P + h->off_wx[l]; g.C = h->dout.as<float>();
-        g.M = R; g.N = h->Ip[l]; g.K = D * N4;
-        g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp; g.split_k = 1;
-        launch_gemm_nt(g, h->st);
-      }
-      // K-contiguous copies of the operands whose contraction index is the row (time) index
-      float* tOut[2] = {h->outT0.as<float>(), h->outT1.as<float>()};
-      launch_transpose(dG, h->dGT.as<float>(), R, D * N4, D * N4, R, ws);
-      if (l == h->L - 1) launch_transpose(h->outb[l].as<float>(), tOut[l & 1], R, D * Hp, D * Hp, R, ws);
-      if (l > 0) launch_transpose(h->outb[l - 1].as<float>(), tOut[(l - 1) & 1], R, D * Hp, D * Hp, R, ws);
-      const float* XT = l == 0 ? h->X0T.as<float>() : tOut[(l - 1) & 1];
-      {  // dWx = X^T dG
-        GemmNTDesc g{};
-        g.A = XT; g.B = h->dGT.as<float>(); g.C = h->G + h->off_wx[l];
-        g.M = h->Ip[l]; g.N = D * N4; g.K = R;
-        g.lda = R; g.ldb = R; g.ldc = D * N4;
-        g.split_k = gemm_pick_split(g.M, g.N, g.K);
-        g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-        if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-        launch_gemm_nt(g, ws);
-      }
-      launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
-      for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
-        GemmNTDesc g{};
-        g.A = tOut[l & 1] + (size_t)d * Hp * R;
-        g.B = h->dGT.as<float>() + (size_t)d * N4 * R;
-        g.C = h->G + h->off_u[(size_t)l * D + d];
-        g.M = Hp; g.N = N4; g.K = R;
-        g.lda = R; g.ldb = R; g.ldc = N4;
-        g.a_kshift = d == 0 ? -Bp : Bp;
-        g.split_k = gemm_pick_split(g.M, g.N, g.K);
-        g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-        if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-        launch_gemm_nt(g, ws);
-      }
-    } else {
-    if (l > 0) {  // critical path first: gradient wrt the layer input = the layer below's output
-      GemmDesc g{};
-      g.A = dG; g.B = h->P + h->off_wx[l]; g.C = h->dout.as<float>();
-      g.M = R; g.N = h->Ip[l]; g.K = D * N4;
-      g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp;
-      g.b_col = true; g.a_rows = R; g.split_k = 1;
-      launch_gemm(g, h->st);
-    }
-    {  // dWx = X^T dG
-      GemmDesc g{};
-      g.A = Xl; g.B = dG; g.C = h->G + h->off_wx[l];
-      g.M = h->Ip[l]; g.N = D * N4; g.K = R;
-      g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
-      g.a_col = true; g.a_rows = R;
-      g.split_k = gemm_pick_split(g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm(g, ws);
-    }
-    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
-    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
-      GemmDesc g{};
-      g.A = h->outb[l].as<float>() + d * Hp;
-      g.B = dG + d * N4;
-      g.C = h->G + h->off_u[(size_t)l * D + d];
-      g.M = Hp; g.N = N4; g.K = R;
-      g.lda = D * Hp; g.ldb = D * N4; g.ldc = N4;
-      g.a_col = true; g.a_shift = d == 0 ? -Bp : Bp; g.a_rows = R;
-      g.split_k = gemm_pick_split(g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm(g, ws);
-    }
-    }
-    if (ws != h->st) HIPCHK(h, hipEventRecord(h->ev_wgrad[l], ws));
-    HIPCHK(h, hipGetLastError());
   }
-  if (ov)
-    for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_wgrad[l], 0));   // join
   h->have_grads = true;
   return NASR_OK;
 }
@@ -830,20 +910,24 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   h->outb.resize(h->L);
   h->cbuf.resize(h->L);
   {
-    // Off by default: measured on MI355X (3x500, B 16, T 500) the weight-gradient GEMMs co-running with the
-    // latency-bound BPTT launches slow those by 30 % and the step gets 0.5 ms LONGER (20.4 vs 19.9 ms).
-    const char* e = getenv("NASR_OVERLAP");
-    h->overlap = (e && e[0] == '1');
-    if (h->overlap && h->L > 1) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) h->side = nullptr;
-      h->ev_bptt.resize(h->L);
-      h->ev_wgrad.resize(h->L);
-      for (int l = 0; l < h->L; ++l) {
-        (void)hipEventCreateWithFlags(&h->ev_bptt[l], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&h->ev_wgrad[l], hipEventDisableTiming);
-      }
+    // Tried and removed (measured on MI355X, 3x500 bi, B 16, T 500): running the weight-gradient GEMMs of layer l on
+    // a low-priority side stream under the BPTT of layer l-1 slowed the latency-bound BPTT launches by 30 % and the
+    // step got 0.5 ms LONGER.  What does pay is pipelining the layers of a UNIdirectional stack, whose step launches
+    // fill only half the CUs: per-layer streams, time chunks, events (NASR_PIPE=0 disables).
+    const char* e = getenv("NASR_PIPE");
+    h->pipe = h->D == 1 && h->L > 1 && !(e && e[0] == '0');
+    const size_t nl = h->pipe ? (size_t)h->L : 1;
+    h->doutL.resize(nl); h->hstateL.resize(nl); h->partialL.resize(nl); h->dcstateL.resize(nl); h->dgL.resize(nl);
+    h->lst.assign((size_t)h->L, h->st);
+    if (h->pipe) {
+      for (int l = 1; l < h->L; ++l)
+        if (hipStreamCreateWithFlags(&h->lst[l], hipStreamNonBlocking) != hipSuccess)
+          return bail(NASR_ERR_HIP, "hipStreamCreate (layer stream) failed");
+      (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+      h->ev_done.resize((size_t)h->L * PIPE_MAX_CHUNKS);
+      h->ev_dx.resize((size_t)h->L * PIPE_MAX_CHUNKS);
+      for (auto& e2 : h->ev_done) (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+      for (auto& e2 : h->ev_dx) (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
     }
   }
   (void)hipEventCreate(&h->ev_total_a);
@@ -858,19 +942,23 @@ int nasr_destroy(nasr_handle h) {
   if (!h) return NASR_OK;
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
-  if (h->side) {
-    (void)hipStreamSynchronize(h->side);
-    (void)hipStreamDestroy(h->side);
-  }
-  for (hipEvent_t e : h->ev_bptt) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->ev_wgrad) (void)hipEventDestroy(e);
+  for (size_t l = 1; l < h->lst.size(); ++l)
+    if (h->lst[l] && h->lst[l] != h->st) {
+      (void)hipStreamSynchronize(h->lst[l]);
+      (void)hipStreamDestroy(h->lst[l]);
+    }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (hipEvent_t e : h->ev_done) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_dx) (void)hipEventDestroy(e);
   drop_graphs(h);
   for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub, h->WxT})
     if (p) (void)hipFree(p);
-  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->dgbuf2, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
+  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
     b->release();
+  for (auto* v : {&h->doutL, &h->hstateL, &h->partialL, &h->dcstateL, &h->dgL})
+    for (auto& b : *v) b.release();
   for (auto& b : h->gates) b.release();
   for (auto& b : h->outb) b.release();
   for (auto& b : h->cbuf) b.release();
