@@ -222,9 +222,11 @@ def main():
             'value': total_frames * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': wname, 'batch_per_gpu': B, 'frames': T, 'feature_size': spec.feature_size,
-                       'hidden': spec.hidden, 'layers': spec.num_layers, 'classes': spec.num_classes,
-                       'var_len': bool(args.var_len), 'parallelism': f'dp{world}', 'hipgraph': not args.no_graph},
+            'config': {'workload': f'{wname}, 16 kHz / 26 MFCC / numcontext 10 (F={spec.feature_size}), '
+                                   f'C={spec.num_classes}, batch {B} per GPU, T={T} frames'
+                                   + (', ragged lengths' if args.var_len else ''),
+                       'batch_per_gpu': B, 'frames': T, 'var_len': bool(args.var_len),
+                       'parallelism': f'dp{world}', 'hipgraph': not args.no_graph},
             'loss': loss,
             'roofline': {'bound': 'hbm', 'kernel': 'lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -156,3 +156,20 @@ def test_device_side_context_stacking_is_bitwise_the_host_stacking():
     broken[:, :, :ncep] = rs.randn(B, T, ncep)
     assert e.upload_batch_context(broken, seq_len, labels, label_len, ctx, ncep) is False
     e.close()
+
+
+@pytest.mark.parametrize("spec", [O.ModelSpec(10, 32, 2, True, 'concat', 6), O.ModelSpec(10, 32, 3, False, 'none', 6)],
+                         ids=['bi2', 'uni3-pipelined'])
+def test_shapes_change_between_steps(spec):
+    """Real training feeds a different (B, T, Lmax) every step: buffers regrow, cached hipGraphs of a shape are reused
+    when it returns, and nothing stale survives a re-allocation."""
+    params = [p.astype(np.float32).astype(np.float64) for p in O.init_params(spec, seed=6)]
+    e = engine_for(spec)
+    e.set_params(O.flatten(params))
+    for (B, T, seed) in [(4, 40, 1), (6, 96, 2), (4, 40, 1), (16, 70, 3), (2, 130, 4), (6, 96, 2), (17, 33, 5)]:
+        feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=seed, var_len=True, Lmin=1, Lmax=max(2, T // 8))
+        lo, _, go, _ = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+        loss, _, g = e.loss_and_grads(feats, seq_len, labels, label_len)
+        assert loss == pytest.approx(lo, rel=3e-5), (B, T)
+        assert rel(g, O.flatten(go)) < 1e-4, (B, T)
+    e.close()
