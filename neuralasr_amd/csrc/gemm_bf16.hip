@@ -9,8 +9,8 @@
 // contraction index is the row index (weights: re-packed after every Adam step; activations / dG: one
 // transpose kernel per layer), see nasr_api.hip.
 //
-// 128x128x32 block tile, 4 waves of 64x64 (2x2 MFMA 32x32 tiles), LDS images [part][row][32 k + 8 pad] bf16
-// (80-byte rows: the 16 lanes of a ds_read_b128 group land on 16 different 16-byte slots), register-staged
+// 128x128x32 block tile, 4 waves of 64x64 (2x2 MFMA 32x32 tiles), XOR-swizzled LDS images [part][row][32 k] bf16
+// (conflict-free for both the ds_write_b64 staging stores and the ds_read_b128 fragment reads), register-staged
 // prefetch of the next k-tile while the current one is multiplied.
 //
 // STATUS (round 1): validated against the f32-MFMA kernel (relative L2 5e-7 .. 2e-6 on the step's shapes,
@@ -21,7 +21,8 @@
 // count alone would give: ablations (NASR_NT_ABL, xproj 8000x4096x1024, 0.49 ms) put the six MFMAs at 40 %, the
 // LDS stores at 40 % and the split arithmetic at 13 % of the time, nearly additive.  Tried and measured slower:
 // issuing the split inside the MFMA stream (spills, 0.50 ms) and a producer/consumer warp-specialised 8-wave
-// form with double-buffered LDS (160 KB => one block per CU, 0.64 ms).
+// form with double-buffered LDS (160 KB => one block per CU, 0.64 ms); an XCD-aware tile order (no change: the
+// operand panels are L2/Infinity-Cache resident either way).
 #include "kernels.h"
 
 #ifndef NASR_NT_ABL
@@ -34,7 +35,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TBM = 128, TBN = 128, TBK = 32, TROW = 40;   // TROW bf16 per LDS row (80 B)
+constexpr int TBM = 128, TBN = 128, TBK = 32, TROW = 32;   // 64-byte LDS rows, XOR-swizzled (see lds_col)
 
 struct GemmNTParams {
   const float* A;
@@ -46,6 +47,14 @@ struct GemmNTParams {
   int split_k, kchunk;
   float* slabs;
 };
+
+// LDS image [part][row][32 k] bf16 with 64-byte rows.  The four 16-byte k-groups of a row are XOR-swizzled with
+// (row >> 2) & 3: a ds_read_b128 lane group (16 rows, same k-group) then lands on 16 different 16-byte slots, and a
+// ds_write_b64 lane group (two consecutive rows) covers all 32 banks exactly once — both conflict-free.  (The
+// unswizzled 80-byte-row image measured 30 B/clk/CU of LDS store throughput, a 2-way write conflict.)
+__device__ __forceinline__ int lds_col(int row, int k) {   // k multiple of 4
+  return (((k >> 3) ^ ((row >> 2) & 3)) << 3) | (k & 7);
+}
 
 __device__ __forceinline__ void split3(const float4 v, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
   const float x[4] = {v.x, v.y, v.z, v.w};
@@ -117,13 +126,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x6_kernel(GemmNTParams p) 
       bf16x4 p1, p2, p3;
       split3(ra[j], p1, p2, p3);
       if ((NASR_NT_ABL & 4) && kt > 0) continue;
-      *reinterpret_cast<bf16x4*>(&As[0][row][4 * kq]) = p1;
-      *reinterpret_cast<bf16x4*>(&As[1][row][4 * kq]) = p2;
-      *reinterpret_cast<bf16x4*>(&As[2][row][4 * kq]) = p3;
+      const int lc = lds_col(row, 4 * kq);
+      *reinterpret_cast<bf16x4*>(&As[0][row][lc]) = p1;
+      *reinterpret_cast<bf16x4*>(&As[1][row][lc]) = p2;
+      *reinterpret_cast<bf16x4*>(&As[2][row][lc]) = p3;
       split3(rb[j], p1, p2, p3);
-      *reinterpret_cast<bf16x4*>(&Bs[0][row][4 * kq]) = p1;
-      *reinterpret_cast<bf16x4*>(&Bs[1][row][4 * kq]) = p2;
-      *reinterpret_cast<bf16x4*>(&Bs[2][row][4 * kq]) = p3;
+      *reinterpret_cast<bf16x4*>(&Bs[0][row][lc]) = p1;
+      *reinterpret_cast<bf16x4*>(&Bs[1][row][lc]) = p2;
+      *reinterpret_cast<bf16x4*>(&Bs[2][row][lc]) = p3;
     }
     __syncthreads();
     if (kt + 1 < nk) NASR_NT_GLOAD(kbeg + (kt + 1) * TBK);   // in flight while this tile is multiplied
@@ -135,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x6_kernel(GemmNTParams p) 
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          a[i][q] = *reinterpret_cast<const bf16x8*>(&As[q][wm + 32 * i + li][16 * s + 8 * lh]);
-          b[i][q] = *reinterpret_cast<const bf16x8*>(&Bs[q][wn + 32 * i + li][16 * s + 8 * lh]);
+          a[i][q] = *reinterpret_cast<const bf16x8*>(&As[q][wm + 32 * i + li][lds_col(wm + 32 * i + li, 16 * s + 8 * lh)]);
+          b[i][q] = *reinterpret_cast<const bf16x8*>(&Bs[q][wn + 32 * i + li][lds_col(wn + 32 * i + li, 16 * s + 8 * lh)]);
         }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
