@@ -62,6 +62,24 @@ void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const floa
                           const float* gates, float* dgbuf, const float* cbuf, const float* dout, const float* dcin,
                           float* dcout, const int* seq_len, hipStream_t st);
 
+// ---- persistent recurrence (lstm_persist.hip): one launch per layer pass, one XCD per (direction, utterance slice) ----
+struct PersistCtl {            // device words, zeroed before every launch
+  unsigned xcc_count[8];       // ticket per XCD: member index of a workgroup inside its group
+  unsigned error;              // bit 0: a bounded spin gave up, bit 1: placement is not 32 workgroups on each of 8 XCDs
+  unsigned pad[23];
+  unsigned flags[8 * 128];     // per group: forward 32 words (one per member), BPTT 128 (member*4 + wave)
+};
+bool persist_supported(int Hp);
+size_t persist_image_floats(int Hp, bool bwd);   // floats of one direction's operand image
+size_t persist_xch_floats(int Hp);               // floats of the exchange buffer (shared by forward and BPTT)
+hipError_t persist_prepare();                    // once per process: raise the kernels' dynamic-LDS limit
+void launch_repack_persist(const float* U, float* Upf, float* Upb, int Hp, hipStream_t st);
+// Upf/Upb: [D] images of this layer; xch: persist_xch_floats(Hp) floats; ctl: one PersistCtl
+void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates, float* cbuf, float* out,
+                             const int* seq_len, float* xch, PersistCtl* ctl, float forget_bias, hipStream_t st);
+void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
+                             const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, hipStream_t st);
+
 // ---- CTC (ctc.hip) ----
 struct CtcDims {
   int Tp;      // logit frames T'
