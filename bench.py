@@ -120,6 +120,7 @@ def main():
     ap.add_argument('--var-len', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--per-step', action='store_true', help='per-timestep launches (lstm.hip) instead of the persistent recurrence')
     args = ap.parse_args()
 
     import torch
@@ -153,6 +154,8 @@ def main():
     eng = Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
                  learning_rate=1e-4, device_id=local, stream=stream)
     eng.set_graph_mode(not args.no_graph)
+    if args.per_step:
+        eng.set_recurrence_mode(False)
     eng.set_params(O.flatten(O.init_params(spec, seed=1)).astype(np.float32))   # same weights on every rank
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1234 + rank, var_len=args.var_len)
     eng.upload_batch(feats, seq_len, labels, label_len)
@@ -204,17 +207,24 @@ def main():
         ms = dt / args.steps * 1e3
         A, W, R = algorithmic_bytes(spec, B, T)
         fb, bb = step_kernel_bytes(spec, B)
+        # persistent recurrence: ONE launch runs all T timesteps of a layer, so a launch's algorithmic bytes are
+        # T x the per-timestep figure of SURVEY.md §8d (which prices the recurrent matrix once per timestep; the
+        # persistent kernels keep it in registers, so the PMC traffic sits far below this figure)
+        persistent = eng.recurrence_mode == 'persistent'
+        spl = T if persistent else 1
         fwd_us = phases['rec_fwd_ms'] * 1e3 / max(phases['rec_fwd_launches'], 1)
         bwd_us = phases['rec_bwd_ms'] * 1e3 / max(phases['rec_bwd_launches'], 1)
         dom_bwd = phases['rec_bwd_ms'] >= phases['rec_fwd_ms']
-        k_bytes, k_us = (bb, bwd_us) if dom_bwd else (fb, fwd_us)
+        k_bytes, k_us = (bb * spl, bwd_us) if dom_bwd else (fb * spl, fwd_us)
         achieved = k_bytes / (k_us * 1e-6) / 1e9
+        kname = ('lstm_persist_bwd_kernel' if dom_bwd else 'lstm_persist_fwd_kernel') if persistent else \
+                ('lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel')
         pmc = None
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc_path):
             try:
                 pj = json.load(open(pmc_path))
-                pmc = pj.get(args.workload, {}).get('lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel')
+                pmc = pj.get(args.workload, {}).get(kname)
             except Exception:
                 pmc = None
         out = {
@@ -226,12 +236,13 @@ def main():
                                    f'C={spec.num_classes}, batch {B} per GPU, T={T} frames'
                                    + (', ragged lengths' if args.var_len else ''),
                        'batch_per_gpu': B, 'frames': T, 'var_len': bool(args.var_len),
-                       'parallelism': f'dp{world}', 'hipgraph': not args.no_graph},
+                       'parallelism': f'dp{world}', 'hipgraph': not args.no_graph,
+                       'recurrence': eng.recurrence_mode},
             'loss': loss,
-            'roofline': {'bound': 'hbm', 'kernel': 'lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel',
+            'roofline': {'bound': 'hbm', 'kernel': kname,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc, 'bytes_per_launch': k_bytes, 'us_per_launch': k_us,
-                         'fwd_step_us': fwd_us, 'bwd_step_us': bwd_us},
+                         'timesteps_per_launch': spl, 'fwd_step_us': fwd_us / spl, 'bwd_step_us': bwd_us / spl},
             'roofline_step': {'bound': 'hbm', 'bytes_alg': A + W + R, 'bytes_compulsory': A + W,
                               'achieved': (A + W + R) / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': (A + W + R) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -68,7 +68,7 @@ typedef struct {
   float wgrad_ms;     /* weight-gradient / input-gradient GEMMs + bias column sums */
   float adam_ms;      /* fused Adam + recurrent-weight repack */
   float total_ms;
-  int32_t rec_fwd_launches; /* number of forward step-kernel launches in rec_fwd_ms */
+  int32_t rec_fwd_launches; /* kernel launches of the recurrence in rec_fwd_ms (T per layer, or 1 when persistent) */
   int32_t rec_bwd_launches;
 } nasr_phase_times;
 
@@ -168,6 +168,13 @@ int nasr_label_error_rate(const int32_t* hyp_ids, const int32_t* hyp_lens, int h
 int nasr_set_profiling(nasr_handle h, int enabled); /* record HIP events around the phases */
 int nasr_get_phase_times(nasr_handle h, nasr_phase_times* out); /* synchronises */
 int nasr_set_graph_mode(nasr_handle h, int enabled); /* capture the per-timestep loops in hipGraphs */
+/* How the recurrence of tf.nn.(bidirectional_)dynamic_rnn (networks/bilstm_ctc_net.py:24-28,
+ * networks/lstm_ctc_net.py:22-23) runs: 1 = one persistent launch per layer pass (one XCD per direction and
+ * utterance slice, recurrent matrix resident in registers), 0 = one launch per timestep.  nasr_set_recurrence_mode(0)
+ * forces the per-step kernels; (1) asks for the persistent ones again and returns NASR_ERR_STATE where the device or
+ * the hidden size does not support them. */
+int nasr_get_recurrence_mode(nasr_handle h);
+int nasr_set_recurrence_mode(nasr_handle h, int persistent);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ SYMBOLS = [
     'nasr_grad_device_ptr', 'nasr_grad_device_count', 'nasr_apply_adam', 'nasr_get_grads', 'nasr_set_grads',
     'nasr_upload_batch_context', 'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_ctc_beam_search', 'nasr_get_loss', 'nasr_resident_frames',
     'nasr_set_profiling', 'nasr_get_phase_times', 'nasr_set_graph_mode',
+    'nasr_get_recurrence_mode', 'nasr_set_recurrence_mode',
 ]
 
 
@@ -104,6 +105,8 @@ def load():
         'nasr_set_profiling': (c_int, [H, c_int]),
         'nasr_get_phase_times': (c_int, [H, POINTER(PhaseTimes)]),
         'nasr_set_graph_mode': (c_int, [H, c_int]),
+        'nasr_get_recurrence_mode': (c_int, [H]),
+        'nasr_set_recurrence_mode': (c_int, [H, c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -74,11 +74,14 @@ size_t persist_image_floats(int Hp, bool bwd);   // floats of one direction's op
 size_t persist_xch_floats(int Hp);               // floats of the exchange buffer (shared by forward and BPTT)
 hipError_t persist_prepare();                    // once per process: raise the kernels' dynamic-LDS limit
 void launch_repack_persist(const float* U, float* Upf, float* Upb, int Hp, hipStream_t st);
-// Upf/Upb: [D] images of this layer; xch: persist_xch_floats(Hp) floats; ctl: one PersistCtl
+// Upf/Upb: [D] images of this layer; xch: persist_xch_floats(Hp) floats; ctl: one PersistCtl (zeroed by the launcher);
+// sticky: host-mapped word that receives the error code of an aborted launch (or NULL)
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates, float* cbuf, float* out,
-                             const int* seq_len, float* xch, PersistCtl* ctl, float forget_bias, hipStream_t st);
+                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float forget_bias,
+                             hipStream_t st);
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
-                             const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, hipStream_t st);
+                             const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
+                             hipStream_t st);
 
 // ---- CTC (ctc.hip) ----
 struct CtcDims {

@@ -65,7 +65,12 @@ __device__ __forceinline__ bool poll_ge(gu32* p, bool active, unsigned want) {
 }
 
 // (xcc id, ticket within the XCD) of this workgroup; false when the placement is not 32-per-XCD-of-8
-__device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* info, unsigned& xcc, unsigned& member) {
+__device__ __forceinline__ void raise_error(PersistCtl* ctl, unsigned* sticky, unsigned code) {
+  atomicOr(&ctl->error, code);
+  if (sticky) __hip_atomic_store(sticky, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible, never cleared by a launch
+}
+
+__device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, unsigned* info, unsigned& xcc, unsigned& member) {
   if (threadIdx.x == 0) {
     const unsigned x = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
     info[0] = x;
@@ -77,7 +82,7 @@ __device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* info, unsi
   xcc = info[0];
   member = info[1];
   if (xcc >= 8 || member >= 32) {
-    if (threadIdx.x == 0) atomicOr(&ctl->error, 2u);
+    if (threadIdx.x == 0) raise_error(ctl, sticky, 2u);
     return false;
   }
   return true;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_kernel(
     const float* __restrict__ Upf,   // [D] images
     float* gates, float* cbuf, float* out, const int* __restrict__ seq_len,
     float* hx,                       // [8 groups][2 parity][Hp*4]
-    PersistCtl* ctl, PersistGeom gm, float fb) {
+    PersistCtl* ctl, unsigned* sticky, PersistGeom gm, float fb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KW = 8 * NU;                 // units (= MFMAs) per wave
   constexpr int NCH = 2 * NU;                // 16-byte chunks (4 units x 1 utterance) per wave and utterance
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_kernel(
   unsigned* info = reinterpret_cast<unsigned*>(lds + LDS_INFO);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   unsigned xcc, member;
-  if (!join_group(ctl, info, xcc, member)) return;
+  if (!join_group(ctl, sticky, info, xcc, member)) return;
   const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D;
   const int NGD = 8 / D, d = (int)xcc / NGD, grp = (int)xcc % NGD;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_kernel(
     }
     if (aborted) break;
   }
-  if (aborted && tid == 0) atomicOr(&ctl->error, 1u);
+  if (aborted && tid == 0) raise_error(ctl, sticky, 1u);
 }
 
 // ------------------------------------------------------------------ BPTT
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
     const float* __restrict__ Upb, const float* __restrict__ gates, float* dgbuf, const float* __restrict__ cbuf,
     const float* __restrict__ dout, const int* __restrict__ seq_len,
     float* px,                      // [8 groups][2 parity][32 consumers][32 producers][64]
-    PersistCtl* ctl, PersistGeom gm) {
+    PersistCtl* ctl, unsigned* sticky, PersistGeom gm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KW = 8 * NU;                  // output units per wave
   constexpr int NOG = (KW + 63) / 64;         // 64-unit output groups per wave
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
   unsigned* info = reinterpret_cast<unsigned*>(lds + LDS_INFO);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   unsigned xcc, member;
-  if (!join_group(ctl, info, xcc, member)) return;
+  if (!join_group(ctl, sticky, info, xcc, member)) return;
   const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D;
   const int NGD = 8 / D, d = (int)xcc / NGD, grp = (int)xcc % NGD;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
     }
     if (aborted) break;
   }
-  if (aborted && tid == 0) atomicOr(&ctl->error, 1u);
+  if (aborted && tid == 0) raise_error(ctl, sticky, 1u);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -465,13 +470,14 @@ hipError_t persist_prepare() {
 }
 
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates, float* cbuf, float* out,
-                             const int* seq_len, float* xch, PersistCtl* ctl, float forget_bias, hipStream_t st) {
+                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float forget_bias,
+                             hipStream_t st) {
   const PersistGeom gm = make_geom(dm);
   (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(256);
 #define NASR_PF(NUV)                                                                                                  \
   hipLaunchKernelGGL((lstm_persist_fwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upf, gates, cbuf, out, seq_len, \
-                     xch, ctl, gm, forget_bias)
+                     xch, ctl, sticky, gm, forget_bias)
   switch (dm.Hp / 32) {
     case 2: NASR_PF(2); break;
     case 4: NASR_PF(4); break;
@@ -482,13 +488,14 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates,
 }
 
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
-                             const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, hipStream_t st) {
+                             const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
+                             hipStream_t st) {
   const PersistGeom gm = make_geom(dm);
   (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(256);
 #define NASR_PB(NUV)                                                                                                   \
   hipLaunchKernelGGL((lstm_persist_bwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upb, gates, dgbuf, cbuf, dout, \
-                     seq_len, xch, ctl, gm)
+                     seq_len, xch, ctl, sticky, gm)
   switch (dm.Hp / 32) {
     case 2: NASR_PB(2); break;
     case 4: NASR_PB(4); break;

@@ -83,6 +83,16 @@ struct nasr_ctx {
   hipEvent_t ev_fork = nullptr;
   std::vector<hipEvent_t> ev_done, ev_dx;   // [layer * PIPE_MAX_CHUNKS + chunk]
   bool gemm_bf16 = true;               // bulk GEMMs on the bf16 matrix cores (fp32-accurate 3-way split), NASR_GEMM=f32 disables
+  // Persistent recurrence (lstm_persist.hip): one launch per layer pass instead of T step launches.  Needs the full
+  // 8 XCD x 32 CU chip and Hp in {64,128,256,512}; NASR_PERSIST=0 keeps the per-step kernels.
+  bool persist = false;
+  bool persist_ok = false;             // the device passed the census at create time
+  bool persist_used = false;           // a persistent launch is in flight since the last check of *perr
+  float *Upf = nullptr, *Upb = nullptr;   // [L][D] operand images
+  size_t imf = 0, imb = 0;             // floats per (layer, direction) image
+  float* xch = nullptr;                // exchange buffer
+  PersistCtl* pctl = nullptr;
+  unsigned* perr = nullptr;            // host-mapped sticky error word
   std::string err;
 
   // model dims
@@ -142,6 +152,26 @@ namespace {
     if (e_ != hipSuccess)                                                                                 \
       return (h)->fail(NASR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
   } while (0)
+
+// A persistent launch that gave up (bounded spin, unexpected placement) leaves its outputs undefined: surface it at
+// the next host sync and use the per-step kernels from then on.
+int persist_check(nasr_ctx* h) {
+  if (!h->persist_used) return NASR_OK;
+  h->persist_used = false;
+  const unsigned code = *reinterpret_cast<volatile unsigned*>(h->perr);
+  if (!code) return NASR_OK;
+  *reinterpret_cast<volatile unsigned*>(h->perr) = 0;
+  h->persist = false;
+  h->persist_ok = false;
+  return h->fail(NASR_ERR_HIP, "persistent recurrence aborted (code " + std::to_string(code) +
+                                   ": 1 = hand-off timeout, 2 = workgroup placement); the results of this step are "
+                                   "invalid, later steps use the per-step kernels");
+}
+
+int sync_checked(nasr_ctx* h) {
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return persist_check(h);
+}
 
 void drop_graphs(nasr_ctx* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -282,6 +312,7 @@ int repack(nasr_ctx* h) {
       const size_t k = (size_t)l * h->D + d;
       const size_t o = k * (size_t)h->Hp * h->N4;
       launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
+      if (h->persist) launch_repack_persist(h->P + h->off_u[k], h->Upf + k * h->imf, h->Upb + k * h->imb, h->Hp, h->st);
     }
   if (h->gemm_bf16)
     for (int l = 0; l < h->L; ++l)
@@ -302,7 +333,7 @@ int scatter_to_device(nasr_ctx* h, const float* tf_flat, float* dev) {
 int gather_from_device(nasr_ctx* h, const float* dev, float* tf_flat) {
   std::vector<float> host((size_t)h->np_int);
   HIPCHK(h, hipMemcpyAsync(host.data(), dev, (size_t)h->np_int * 4, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
+  if (int rc = sync_checked(h)) return rc;
   for (int64_t i = 0; i < h->np_tf; ++i) tf_flat[i] = host[(size_t)h->tf2int[(size_t)i]];
   return NASR_OK;
 }
@@ -358,7 +389,7 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   if (!ok) return h->fail(NASR_ERR_HIP, "hipMalloc failed while sizing batch buffers");
   if (grew || Bp != h->Bp) drop_graphs(h);
   // pipeline the layers of a unidirectional stack over time chunks of >= 32 frames
-  h->pipe_chunks = h->pipe ? std::max(1, std::min(PIPE_MAX_CHUNKS, std::min(10, T / 32))) : 1;
+  h->pipe_chunks = (h->pipe && !h->persist) ? std::max(1, std::min(PIPE_MAX_CHUNKS, std::min(10, T / 32))) : 1;
   h->B = B; h->Bp = Bp; h->T = T; h->Lmax = Lmax; h->Tp = Tp; h->KS = KSa;
   return NASR_OK;
 }
@@ -472,6 +503,18 @@ inline hipStream_t stream_of(nasr_ctx* h, int l) { return (h->pipe_chunks > 1 &&
 // ---- the per-timestep loops over steps [s0, s1), optionally replayed from a hipGraph -----------
 int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
   const LstmDims dm{h->T, h->B, h->Bp, h->H, h->Hp, h->D};
+  if (h->persist && s0 == 0 && s1 == h->T) {
+    const size_t k = (size_t)l * h->D;
+    if (!bwd)
+      launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->gates[l].as<float>(), h->cbuf[l].as<float>(),
+                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->cfg.forget_bias, st);
+    else
+      launch_lstm_persist_bwd(dm, h->Upb + k * h->imb, h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(),
+                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl, h->perr, st);
+    h->persist_used = true;
+    HIPCHK(h, hipGetLastError());
+    return NASR_OK;
+  }
   const size_t sU = (size_t)l * h->D * h->Hp * h->N4;
   const size_t hs = (size_t)h->D * h->Bp * h->Hp;   // one h-state image
   const size_t ps = (size_t)h->D * (h->Hp / 32) * h->Bp * h->Hp;   // one partial-sum image
@@ -588,7 +631,7 @@ int forward(nasr_ctx* h) {
       PhaseScope ps(h, PH_RECF);
       int rc = run_steps(h, l, false, 0, T, h->st);
       if (rc) return rc;
-      h->n_fwd_launch += T;
+      h->n_fwd_launch += h->persist ? 1 : T;
     }
   } else {
     // layer l, chunk c needs layer l-1's chunk c and its own chunk c-1 (same stream)
@@ -771,7 +814,7 @@ int backward(nasr_ctx* h) {
         PhaseScope ps(h, PH_RECB);
         int rc = run_steps(h, l, true, 0, T, h->st);
         if (rc) return rc;
-        h->n_bwd_launch += T;
+        h->n_bwd_launch += h->persist ? 1 : T;
       }
       PhaseScope ps(h, PH_WGRAD);
       if (l > 0) gemm_dx(h, l, 0, R, h->st);   // critical path first
@@ -815,7 +858,7 @@ int fetch_logits(nasr_ctx* h, float* logits_out) {
   const size_t n = (size_t)h->Tp * h->Bp * h->Cp;
   std::vector<float> host(n);
   HIPCHK(h, hipMemcpyAsync(host.data(), h->logits.p, n * 4, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
+  if (int rc = sync_checked(h)) return rc;
   for (int t = 0; t < h->Tp; ++t)
     for (int b = 0; b < h->B; ++b)
       memcpy(logits_out + ((size_t)t * h->B + b) * h->C, host.data() + ((size_t)t * h->Bp + b) * h->Cp,
@@ -906,6 +949,25 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   (void)hipMemsetAsync(h->G, 0, nb, h->st);
   (void)hipMemsetAsync(h->Uf, 0, ub, h->st);
   (void)hipMemsetAsync(h->Ub, 0, ub, h->st);
+  {
+    const char* e = getenv("NASR_PERSIST");
+    h->persist = !(e && e[0] == '0') && persist_supported(h->Hp) && prop.multiProcessorCount == 256;
+    if (h->persist) {
+      h->imf = persist_image_floats(h->Hp, false);
+      h->imb = persist_image_floats(h->Hp, true);
+      const size_t nk = (size_t)h->L * h->D;
+      if (persist_prepare() != hipSuccess || hipMalloc(&h->Upf, nk * h->imf * 4) != hipSuccess ||
+          hipMalloc(&h->Upb, nk * h->imb * 4) != hipSuccess ||
+          hipMalloc(&h->xch, persist_xch_floats(h->Hp) * 4) != hipSuccess ||
+          hipMalloc(&h->pctl, sizeof(PersistCtl)) != hipSuccess ||
+          hipHostMalloc(&h->perr, 64, hipHostMallocMapped) != hipSuccess)
+        return bail(NASR_ERR_HIP, "allocation of the persistent-recurrence buffers failed");
+      *h->perr = 0;
+      (void)hipMemsetAsync(h->Upf, 0, nk * h->imf * 4, h->st);
+      (void)hipMemsetAsync(h->Upb, 0, nk * h->imb * 4, h->st);
+      (void)hipMemsetAsync(h->xch, 0, persist_xch_floats(h->Hp) * 4, h->st);
+    }
+  }
   h->gates.resize(h->L);
   h->outb.resize(h->L);
   h->cbuf.resize(h->L);
@@ -915,7 +977,7 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     // step got 0.5 ms LONGER.  What does pay is pipelining the layers of a UNIdirectional stack, whose step launches
     // fill only half the CUs: per-layer streams, time chunks, events (NASR_PIPE=0 disables).
     const char* e = getenv("NASR_PIPE");
-    h->pipe = h->D == 1 && h->L > 1 && !(e && e[0] == '0');
+    h->pipe = h->D == 1 && h->L > 1 && !(e && e[0] == '0') && !h->persist;
     const size_t nl = h->pipe ? (size_t)h->L : 1;
     h->doutL.resize(nl); h->hstateL.resize(nl); h->partialL.resize(nl); h->dcstateL.resize(nl); h->dgL.resize(nl);
     h->lst.assign((size_t)h->L, h->st);
@@ -934,6 +996,34 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   (void)hipEventCreate(&h->ev_total_b);
   memset(&h->last_times, 0, sizeof(h->last_times));
   if (hipStreamSynchronize(h->st) != hipSuccess) return bail(NASR_ERR_HIP, "stream synchronize failed in create");
+  if (h->persist) {
+    // Census: two steps of both persistent kernels on a zero layer.  A chip that does not place 32 workgroups on each of
+    // its 8 XCDs (partition modes, masked CUs, a co-tenant) is detected here and served by the per-step kernels.
+    const int Bp = 16, T = 2;
+    const size_t R = (size_t)T * Bp;
+    DevBuf g, c, o, dg, sq;
+    bool grew = false;
+    bool ok = g.ensure(R * h->D * h->N4 * 4, &grew) && c.ensure(R * h->D * h->Hp * 4, &grew) &&
+              o.ensure(R * h->D * h->Hp * 4, &grew) && dg.ensure(R * h->D * h->N4 * 4, &grew) && sq.ensure(Bp * 4, &grew);
+    if (ok) {
+      (void)hipMemsetAsync(g.p, 0, R * h->D * h->N4 * 4, h->st);
+      (void)hipMemsetAsync(o.p, 0, R * h->D * h->Hp * 4, h->st);
+      std::vector<int32_t> two((size_t)Bp, T);
+      (void)hipMemcpyAsync(sq.p, two.data(), Bp * 4, hipMemcpyHostToDevice, h->st);
+      const LstmDims dm{T, Bp, Bp, h->H, h->Hp, h->D};
+      launch_lstm_persist_fwd(dm, h->Upf, g.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(), h->xch, h->pctl,
+                              h->perr, 1.f, h->st);
+      launch_lstm_persist_bwd(dm, h->Upb, g.as<float>(), dg.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(),
+                              h->xch, h->pctl, h->perr, h->st);
+      ok = hipStreamSynchronize(h->st) == hipSuccess && hipGetLastError() == hipSuccess && *h->perr == 0;
+    }
+    for (DevBuf* b : {&g, &c, &o, &dg, &sq}) b->release();
+    if (!ok) {
+      *h->perr = 0;
+      h->persist = false;
+    }
+    h->persist_ok = h->persist;
+  }
   *out = h;
   return NASR_OK;
 }
@@ -951,8 +1041,10 @@ int nasr_destroy(nasr_handle h) {
   for (hipEvent_t e : h->ev_done) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_dx) (void)hipEventDestroy(e);
   drop_graphs(h);
-  for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub, h->WxT})
+  for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub, h->WxT, h->Upf, h->Upb, h->xch})
     if (p) (void)hipFree(p);
+  if (h->pctl) (void)hipFree(h->pctl);
+  if (h->perr) (void)hipHostFree(h->perr);
   for (DevBuf* b : {&h->feats_bm, &h->X0, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
@@ -975,8 +1067,7 @@ const char* nasr_backend(nasr_handle) { return "hip-gfx950"; }
 
 int nasr_synchronize(nasr_handle h) {
   if (!h) return NASR_ERR_ARG;
-  HIPCHK(h, hipStreamSynchronize(h->st));
-  return NASR_OK;
+  return sync_checked(h);
 }
 
 int64_t nasr_param_count(nasr_handle h) { return h ? h->np_tf : -1; }
@@ -1160,8 +1251,7 @@ int nasr_label_error_rate(const int32_t* hyp_ids, const int32_t* hyp_lens, int h
 int nasr_get_loss(nasr_handle h, float* loss_out) {
   if (!h || !loss_out) return NASR_ERR_ARG;
   HIPCHK(h, hipMemcpyAsync(loss_out, h->loss.p, 4, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
-  return NASR_OK;
+  return sync_checked(h);
 }
 
 int nasr_resident_frames(nasr_handle h, int64_t* frames) {
@@ -1240,8 +1330,7 @@ int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(lens_out, h->lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipMemcpyAsync(ids_out, h->ids.p, (size_t)B * h->Tp * 4, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
-  return NASR_OK;
+  return sync_checked(h);
 }
 
 int nasr_set_step_decode(nasr_handle h, int enabled) {
@@ -1255,8 +1344,7 @@ int nasr_get_decoded(nasr_handle h, int32_t* ids_out, int32_t* lens_out) {
   if (!h->have_decoded) return h->fail(NASR_ERR_STATE, "nasr_get_decoded: no decoded step (enable nasr_set_step_decode)");
   HIPCHK(h, hipMemcpyAsync(lens_out, h->lens.p, (size_t)h->B * 4, hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipMemcpyAsync(ids_out, h->ids.p, (size_t)h->B * h->Tp * 4, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
-  return NASR_OK;
+  return sync_checked(h);
 }
 
 int nasr_set_profiling(nasr_handle h, int enabled) {
@@ -1294,6 +1382,18 @@ int nasr_set_graph_mode(nasr_handle h, int enabled) {
   if (!h) return NASR_ERR_ARG;
   h->graph_mode = enabled != 0;
   if (!h->graph_mode) drop_graphs(h);
+  return NASR_OK;
+}
+
+int nasr_get_recurrence_mode(nasr_handle h) { return h && h->persist ? 1 : 0; }
+
+int nasr_set_recurrence_mode(nasr_handle h, int persistent) {
+  if (!h) return NASR_ERR_ARG;
+  if (persistent && !h->persist_ok)
+    return h->fail(NASR_ERR_STATE, "the persistent recurrence is not available on this device / hidden size");
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  h->persist = persistent != 0;
+  if (h->persist) return repack(h);
   return NASR_OK;
 }
 

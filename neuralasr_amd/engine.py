@@ -275,6 +275,14 @@ class Engine:
     def set_graph_mode(self, on):
         self._ck(self.lib.nasr_set_graph_mode(self.h, int(bool(on))))
 
+    @property
+    def recurrence_mode(self):
+        """'persistent' (one launch per layer pass, lstm_persist.hip) or 'per-step' (lstm.hip)."""
+        return 'persistent' if self.lib.nasr_get_recurrence_mode(self.h) else 'per-step'
+
+    def set_recurrence_mode(self, persistent):
+        self._ck(self.lib.nasr_set_recurrence_mode(self.h, int(bool(persistent))))
+
     def phase_times(self):
         pt = _lib.PhaseTimes()
         self._ck(self.lib.nasr_get_phase_times(self.h, byref(pt)))
