@@ -35,9 +35,42 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef NASR_PABL
+#define NASR_PABL 0     // timing experiments only (results wrong): 1 = forward without its side stores and prefetch
+#endif
+#ifndef NASR_PSTAMP
+#define NASR_PSTAMP 0   // 1: wave 0 of one workgroup accumulates s_memtime deltas per phase into PersistCtl::pad (tools/persistbench)
+#endif
+
 namespace nasr {
 
 namespace {
+
+struct Stamps {
+  unsigned long long last;
+  unsigned acc[12];
+  bool on;
+  __device__ __forceinline__ void start(bool enable) {
+    on = enable;
+    for (int i = 0; i < 12; ++i) acc[i] = 0;
+    last = NASR_PSTAMP ? __builtin_amdgcn_s_memtime() : 0ull;
+  }
+  __device__ __forceinline__ void mark(int i) {
+#if NASR_PSTAMP
+    if (on) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      acc[i] += (unsigned)(t - last);
+      last = t;
+    }
+#endif
+  }
+  __device__ __forceinline__ void flush(PersistCtl* ctl) {
+#if NASR_PSTAMP
+    if (on && (threadIdx.x & 63) == 0)
+      for (int i = 0; i < 12; ++i) ctl->pad[i] = acc[i];
+#endif
+  }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -77,6 +110,7 @@ __device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, un
     info[1] = x < 8 ? atomicAdd(&ctl->xcc_count[x], 1u) : 0xffffu;
     info[2] = 0;
     info[3] = 0;
+    info[4] = 0;
   }
   __syncthreads();
   xcc = info[0];
@@ -140,11 +174,20 @@ struct PersistGeom {
 
 constexpr int PERSIST_LDS_BYTES = 96 * 1024;   // > half of the CU's 160 KB: one workgroup per CU
 
-// LDS map (floats): red [2][4][4][64] | adg [2][256] | info[8]
-constexpr int LDS_RED = 0, LDS_ADG = 2 * 4 * 4 * 64, LDS_INFO = LDS_ADG + 2 * 256;
+// LDS map (floats): red [2][4][4][64] | adg [2][256] | side [2][64][8] | xgb [2][64][4] | pfb [2][64][8] | info[8]
+constexpr int LDS_RED = 0, LDS_ADG = 2 * 4 * 4 * 64, LDS_SIDE = LDS_ADG + 2 * 256, LDS_XGB = LDS_SIDE + 2 * 64 * 8,
+              LDS_PFB = LDS_XGB + 2 * 64 * 4, LDS_INFO = LDS_PFB + 2 * 64 * 8;   // info: 16 words
+
+// Wave roles inside a workgroup (320 threads): waves 0-3 run the MFMA part, each with a quarter of the CU's slice of
+// the recurrent matrix in registers; wave 0 (the CELL wave) additionally does the 64 cell updates and publishes the
+// state; wave 4 (the MEMORY wave) owns every HBM access that is not part of the hand-off: it loads the next step's
+// per-frame operands ahead of time and passes them to the cell wave through LDS, and it stores the per-frame results
+// (activations, c, out / dG) from LDS one step later.  It does this while the other waves are in their MFMA phase,
+// when the memory system is otherwise idle.  Measured (forward, us per step): loads and stores in the cell wave 1.69,
+// in an MFMA wave right after the publish 1.64 (they compete with the hand-off), none at all 1.46.
 
 template <int NU>
-__global__ __launch_bounds__(256, 1) void lstm_persist_fwd_kernel(
+__global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
     const float* __restrict__ Upf,   // [D] images
     float* gates, float* cbuf, float* out, const int* __restrict__ seq_len,
     float* hx,                       // [8 groups][2 parity][Hp*4]
@@ -154,6 +197,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_kernel(
   constexpr int NCH = 2 * NU;                // 16-byte chunks (4 units x 1 utterance) per wave and utterance
   constexpr int NJ = (NCH + 15) / 16;        // 16-byte loads per lane
   float* red = lds + LDS_RED;
+  float* side = lds + LDS_SIDE;
+  float* xgb = lds + LDS_XGB;
   unsigned* info = reinterpret_cast<unsigned*>(lds + LDS_INFO);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   unsigned xcc, member;
@@ -161,10 +206,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_kernel(
   const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D;
   const int NGD = 8 / D, d = (int)xcc / NGD, grp = (int)xcc % NGD;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
+  // the memory wave shares a SIMD with one of the MFMA waves: it only gets the issue slots that wave leaves free
+  if (w < 4) __builtin_amdgcn_s_setprio(3);
 
   // this wave's slice of the recurrent matrix, resident for the whole launch
   float wreg[KW];
-  {
+  if (w < 4) {
     const float* wp = Upf + ((((size_t)d * 32 + member) * 4 + w) * KW) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < KW; ++i) wreg[i] = wp[(size_t)i * 64];
@@ -172,116 +219,163 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_fwd_kernel(
   float* ghx = hx + (size_t)xcc * 2 * Hp * 4;
   gu32* gflag = (gu32*)(ctl->flags + xcc * 128);
 
-  // cell lanes (wave 0): lane = 16*q + u -> utterance slot q, unit NU*member + u
+  // cell decomposition, the same in every wave: lane = 16*q + u -> utterance slot q, unit NU*member + u
   const int q = lane >> 4, u = lane & 15;
-  const bool cell_lane = w == 0 && u < NU;
+  const bool lane_ok = u < NU;
   const int j = NU * (int)member + u;
+  const int jcl = j < Hp ? j : Hp - 1;
   const int hidx = (j >> 2) * 16 + q * 4 + (j & 3);
   bool aborted = false;
+  Stamps stp;
+  stp.start(w == 0 && xcc == 0 && member == 0);
 
   for (int rd = 0; rd < gm.rounds; ++rd) {
     const int b0 = (rd * NGD + grp) * gm.ub;
     if (b0 >= Bp) continue;                       // uniform over the group
     const int b = b0 + q;
-    const bool rowok = cell_lane && q < gm.ub && b < Bp;
+    const bool rowok = lane_ok && q < gm.ub && b < Bp;
+    const int bcl = b < Bp ? b : Bp - 1;
     const int len = rowok ? seq_len[b] : 0;
     const unsigned tagbase = (unsigned)(rd * T);
     float c = 0.f;
-    float4 xg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rowok && 0 < len) {
-      const int tb = d ? len - 1 : 0;
-      xg = *reinterpret_cast<const float4*>(gates + ((size_t)tb * Bp + b) * DN + d * N4 + 4 * j);
-    }
+    // memory wave: gate pre-activations of frame(s), loaded a step ahead.  UNCONDITIONAL loads (lanes without a valid
+    // frame read a clamped address, the value is never used): a load under a divergent branch makes hipcc copy its
+    // result into loop-carried registers right away, i.e. wait for it on the spot.
+    // element offsets fit 32 bits (T*Bp*D*N4 < 2^32 is checked by the launcher): cheap address arithmetic
+    const unsigned xoff = (unsigned)bcl * (unsigned)DN + (unsigned)(d * N4 + 4 * jcl), xstep = (unsigned)Bp * (unsigned)DN;
+    auto frame_of = [&](int s) { return (rowok && s < len) ? (d ? len - 1 - s : s) : 0; };
+    auto load_xg = [&](int s) { return *reinterpret_cast<const f32x4*>(gates + (xoff + (unsigned)frame_of(s) * xstep)); };
+    f32x4 xg_pf = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (w == 4) xg_pf = load_xg(0);
+    // results of step s-1 (activations, c, h) leave through the memory wave one step later
+    auto store_side = [&](int s) {   // memory wave, after the barrier that follows the cell update of step s
+      if (rowok) {
+        if (s < len) {
+          const float* sp = side + ((s & 1) * 64 + lane) * 8;
+          const f32x4 act = *reinterpret_cast<const f32x4*>(sp);
+          const float2 ch = *reinterpret_cast<const float2*>(sp + 4);
+          const unsigned r = (unsigned)((d ? (len - 1 - s) : s) * Bp + b);
+          *reinterpret_cast<f32x4*>(gates + (r * (unsigned)DN + (unsigned)(d * N4 + 4 * j))) = act;
+          const unsigned oc = r * (unsigned)DH + (unsigned)(d * Hp + j);
+          cbuf[oc] = ch.x;
+          out[oc] = ch.y;
+        } else {
+          out[(unsigned)(s * Bp + b) * (unsigned)DH + (unsigned)(d * Hp + j)] = 0.f;   // frame s is past seq_len in both directions
+        }
+      }
+    };
     for (int s = 0; s < T; ++s) {
       const int par = s & 1;
-      // 1. the 8 producers of this wave's K quarter have published h_{s-1} (and finished with h_{s-2})
-      const bool ok = poll_ge(gflag + w * 8 + (lane & 7), lane < 8, tagbase + (unsigned)s);
-      f32x4 acc[4];
+      stp.mark(0);
+      bool ok = true;
+      if (w < 4) {
+        // 1. the 8 producers of this wave's K quarter have published h_{s-1} (and finished with h_{s-2})
+        ok = poll_ge(gflag + w * 8 + (lane & 7), lane < 8, tagbase + (unsigned)s);
+        stp.mark(1);
+        f32x4 acc[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (s > 0 && ok) {
-        // 2. h_{s-1} of this K quarter: chunk = (unit/4)*4 + utterance, 16 B = 4 consecutive units
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 P[NJ];
-        const float* src = ghx + (size_t)((s - 1) & 1) * Hp * 4 + ((size_t)w * KW * 4 + (size_t)lane * 4);
-        if constexpr (NJ == 2) {
-          asm volatile(
-              "global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
-              : "=&v"(P[0]), "=&v"(P[1])
-              : "v"(src)
-              : "memory");
-        } else {
-          P[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (lane < 4 * NCH)
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(P[0]) : "v"(src) : "memory");
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) P[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0 && ok) {
+          // 2. h_{s-1} of this K quarter: chunk = (unit/4)*4 + utterance, 16 B = 4 consecutive units
+          const float* src = ghx + (size_t)((s - 1) & 1) * Hp * 4 + ((size_t)w * KW * 4 + (size_t)lane * 4);
+          if constexpr (NJ == 2) {
+            asm volatile(
+                "global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                : "=&v"(P[0]), "=&v"(P[1])
+                : "v"(src)
+                : "memory");
+          } else {
+            if (lane < 4 * NCH)
+              asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(P[0]) : "v"(src) : "memory");
+          }
         }
-        // 3. acc[.][utt] (16 units x 4 gates) += h[utt][k] * U[k][cols]; A broadcast from block bb%16
-        static_for<0, NCH>([&](auto bbc) {
-          constexpr int bb = decltype(bbc)::value;
-          static_for<0, 4>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[bb / 16][r], wreg[bb * 4 + r], acc[r], 4, bb % 16, 0);
+        if (w == 0 && lane == 0) *reinterpret_cast<volatile unsigned*>(info + 4) = tagbase + (unsigned)s + 1u;   // MFMA phase starts
+        stp.mark(2);
+        if (s > 0 && ok) {
+          // 3. acc[.][utt] (16 units x 4 gates) += h[utt][k] * U[k][cols]; A broadcast from block bb%16
+          static_for<0, NCH>([&](auto bbc) {
+            constexpr int bb = decltype(bbc)::value;
+            static_for<0, 4>([&](auto rc) {
+              constexpr int r = decltype(rc)::value;
+              acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[bb / 16][r], wreg[bb * 4 + r], acc[r], 4, bb % 16, 0);
+            });
           });
-        });
-      }
-      {
+        }
         const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         float* rw = red + ((par * 4 + w) * 4) * 64 + lane;
         rw[0] = sum[0]; rw[64] = sum[1]; rw[128] = sum[2]; rw[192] = sum[3];
+        if (!ok) info[2 + par] = 1;
+      } else {
+        // memory wave: hand the gates of frame(s) to the cell wave, then - once the MFMA waves have their operands and
+        // the hand-off traffic is over - load the gates of frame(s+1) and store the results of step s-1.  (Measured
+        // alternatives, forward us/step with stamps: this 1.645; right after the cell update, i.e. beside the
+        // hand-off, 1.74; in an MFMA wave 1.64; in the cell wave 1.69.)
+        *reinterpret_cast<f32x4*>(xgb + (par * 64 + lane) * 4) = xg_pf;
+        const unsigned want = tagbase + (unsigned)s + 1u;
+        for (unsigned n = 0; n < (1u << 26) && (int)(*reinterpret_cast<volatile unsigned*>(info + 4) - want) < 0; ++n)
+          __builtin_amdgcn_s_sleep(1);
+        if (s + 1 < T) xg_pf = load_xg(s + 1);     // the load first: its wait must not sit behind the stores' acknowledgements
+        if (s > 0) store_side(s - 1);
       }
-      if (!ok) info[2 + par] = 1;
+      stp.mark(3);
+#if NASR_PSTAMP
+      if (lane == 0) info[8 + w] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
+      stp.mark(4);
+#if NASR_PSTAMP
+      if (stp.on) for (int i = 1; i < 5; ++i) stp.acc[6 + i] += info[8 + i] - info[8];   // arrival of wave i after wave 0 (mod 2^32)
+#endif
       if (info[2 + par]) { aborted = true; break; }
-      // 4. cell update: wave 0, lane = (utterance q, unit u)
       if (w == 0) {
+        // 4. cell update: lane = (utterance q, unit u)
         const bool valid = rowok && s < len;
         float h = 0.f;
-        float4 act = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cell_lane) {
+        if (lane_ok) {
           const float* rr = red + (par * 4 * 4 + q) * 64 + 4 * u;
-          const float4 g0 = *reinterpret_cast<const float4*>(rr);
-          const float4 g1 = *reinterpret_cast<const float4*>(rr + 256);
-          const float4 g2 = *reinterpret_cast<const float4*>(rr + 512);
-          const float4 g3 = *reinterpret_cast<const float4*>(rr + 768);
-          act.x = psig(xg.x + ((g0.x + g1.x) + (g2.x + g3.x)));
-          act.y = ptanh(xg.y + ((g0.y + g1.y) + (g2.y + g3.y)));
-          act.z = psig(xg.z + ((g0.z + g1.z) + (g2.z + g3.z)) + fb);
-          act.w = psig(xg.w + ((g0.w + g1.w) + (g2.w + g3.w)));
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(rr);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(rr + 256);
+          const f32x4 g2 = *reinterpret_cast<const f32x4*>(rr + 512);
+          const f32x4 g3 = *reinterpret_cast<const f32x4*>(rr + 768);
+          const f32x4 xg = *reinterpret_cast<const f32x4*>(xgb + (par * 64 + lane) * 4);
+          const f32x4 pre = xg + ((g0 + g1) + (g2 + g3));
+          f32x4 act;
+          act.x = psig(pre.x);
+          act.y = ptanh(pre.y);
+          act.z = psig(pre.z + fb);
+          act.w = psig(pre.w);
           if (valid) {
             c = c * act.z + act.x * act.y;
             h = ptanh(c) * act.w;
           }
           ghx[(size_t)par * Hp * 4 + hidx] = h;          // plain store: lands in this XCD's L2
+          float* sp = side + (par * 64 + lane) * 8;
+          *reinterpret_cast<f32x4*>(sp) = act;
+          *reinterpret_cast<float2*>(sp + 4) = make_float2(c, h);
         }
+        stp.mark(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and is acknowledged before the flag goes out
+        stp.mark(6);
         if (lane == 0) *(ctl->flags + xcc * 128 + member) = tagbase + (unsigned)s + 1u;
-        if (rowok) {
-          if (valid) {
-            const int tb = d ? (len - 1 - s) : s;
-            const size_t r = (size_t)tb * Bp + b;
-            *reinterpret_cast<float4*>(gates + r * DN + d * N4 + 4 * j) = act;
-            cbuf[r * DH + d * Hp + j] = c;
-            out[r * DH + d * Hp + j] = h;
-          } else {
-            out[((size_t)s * Bp + b) * DH + d * Hp + j] = 0.f;   // frame s is past seq_len in both directions
-          }
-          if (s + 1 < len) {
-            const int tb = d ? (len - 2 - s) : s + 1;
-            xg = *reinterpret_cast<const float4*>(gates + ((size_t)tb * Bp + b) * DN + d * N4 + 4 * j);
-          }
-        }
       }
     }
     if (aborted) break;
+    __syncthreads();                  // the last cell update's results are in LDS
+    if (w == 4) store_side(T - 1);
   }
+  stp.flush(ctl);
   if (aborted && tid == 0) raise_error(ctl, sticky, 1u);
 }
 
 // ------------------------------------------------------------------ BPTT
 template <int NU>
-__global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
+__global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
     const float* __restrict__ Upb, const float* __restrict__ gates, float* dgbuf, const float* __restrict__ cbuf,
     const float* __restrict__ dout, const int* __restrict__ seq_len,
-    float* px,                      // [8 groups][2 parity][32 consumers][32 producers][64]
+    float* px,                      // [8 groups][2 parity][32 consumers][32 producers][16 units][4 utterances]
     PersistCtl* ctl, unsigned* sticky, PersistGeom gm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KW = 8 * NU;                  // output units per wave
@@ -289,6 +383,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
   constexpr int NC = 4 * NU;                  // gate columns this CU contracts
   constexpr int NV = (NC + 15) / 16;          // A registers
   float* adg = lds + LDS_ADG;
+  float* pfb = lds + LDS_PFB;
   unsigned* info = reinterpret_cast<unsigned*>(lds + LDS_INFO);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   unsigned xcc, member;
@@ -296,9 +391,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
   const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D;
   const int NGD = 8 / D, d = (int)xcc / NGD, grp = (int)xcc % NGD;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
+  // the memory wave shares a SIMD with one of the MFMA waves: it only gets the issue slots that wave leaves free
+  if (w < 4) __builtin_amdgcn_s_setprio(3);
 
   float wreg[NOG * NC];
-  {
+  if (w < 4) {
     const float* wp = Upb + ((((size_t)d * 32 + member) * 4 + w) * (NOG * NC)) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < NOG * NC; ++i) wreg[i] = wp[(size_t)i * 64];
@@ -306,42 +403,79 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
   float* gpx = px + (size_t)xcc * 2 * 32 * 32 * 64;
   gu32* gflag = (gu32*)(ctl->flags + xcc * 128);
 
-  const int q = lane >> 4, u = lane & 15;
-  const bool cell_lane = w == 0 && u < NU;
+  const int q = lane & 3, u = lane >> 2;        // cell decomposition: lane = 4*u + q, the order of an exchange row
+  const bool lane_ok = u < NU;
   const int j = NU * (int)member + u;
+  const int jcl = j < Hp ? j : Hp - 1;
   bool aborted = false;
+  Stamps stp;
+  stp.start(w == 0 && xcc == 0 && member == 0);
 
   for (int rd = 0; rd < gm.rounds; ++rd) {
     const int b0 = (rd * NGD + grp) * gm.ub;
     if (b0 >= Bp) continue;
     const int b = b0 + q;
-    const bool rowok = cell_lane && q < gm.ub && b < Bp;
+    const bool rowok = lane_ok && q < gm.ub && b < Bp;
+    const int bcl = b < Bp ? b : Bp - 1;
     const int len = rowok ? seq_len[b] : 0;
     const unsigned tagbase = (unsigned)(rd * T);
     float dc = 0.f;
-    // operands of the step about to run (prefetched a step ahead): activations, c, c of the previous frame, dOut
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cc = 0.f, cpv = 0.f, dha = 0.f;
+    // memory wave: the operands of step s (activations, c, c of the frame the forward pass visited before, dOut),
+    // loaded two steps ahead, unconditionally (clamped address on lanes without a valid frame, value unused there)
+    f32x4 pa = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 pb = (f32x4){0.f, 0.f, 0.f, 0.f};   // cc, cpv, dOut, -
     auto prefetch = [&](int s) {
-      if (rowok && s < len) {
-        const int tb = d ? (len - 1 - s) : s;
-        const size_t r = (size_t)tb * Bp + b;
-        a = *reinterpret_cast<const float4*>(gates + r * DN + d * N4 + 4 * j);
-        cc = cbuf[r * DH + d * Hp + j];
-        cpv = s > 0 ? cbuf[(d ? r + Bp : r - Bp) * DH + d * Hp + j] : 0.f;
-        dha = dout[r * DH + d * Hp + j];
+      const bool v = rowok && s < len;
+      const int tb = v ? (d ? (len - 1 - s) : s) : 0;
+      const unsigned r = (unsigned)(tb * Bp + bcl);
+      const unsigned rp = (v && s > 0) ? (d ? r + (unsigned)Bp : r - (unsigned)Bp) : r;
+      const unsigned cj = (unsigned)(d * Hp + jcl);
+      pa = *reinterpret_cast<const f32x4*>(gates + (r * (unsigned)DN + (unsigned)(d * N4 + 4 * jcl)));
+      pb.x = cbuf[r * (unsigned)DH + cj];
+      pb.y = cbuf[rp * (unsigned)DH + cj];
+      pb.z = dout[r * (unsigned)DH + cj];
+    };
+    auto hand_over = [&](int k) {   // operands of step k -> LDS, read by the cell wave after the next barrier
+      float* dst = pfb + ((k & 1) * 64 + lane) * 8;
+      *reinterpret_cast<f32x4*>(dst) = pa;
+      *reinterpret_cast<f32x4*>(dst + 4) = pb;
+    };
+    auto store_dg = [&](int k) {    // memory wave: frame-indexed dG of step k (zero at masked frames) from the A image
+      if (rowok) {
+        const int s = T - 1 - k;
+        const float* ad = adg + (k & 1) * 256 + 16 * u + q;
+        const f32x4 dg = (f32x4){ad[0], ad[4], ad[8], ad[12]};
+        const unsigned row = (unsigned)(((s < len) ? (d ? (len - 1 - s) : s) : s) * Bp + b);
+        *reinterpret_cast<f32x4*>(dgbuf + (row * (unsigned)DN + (unsigned)(d * N4 + 4 * j))) = dg;
       }
     };
-    prefetch(T - 1);
+    if (w == 4) {
+      prefetch(T - 1);
+      hand_over(0);
+      if (T > 1) prefetch(T - 2);
+    }
+    __syncthreads();
     for (int k = 0; k < T; ++k) {
       const int s = T - 1 - k, par = k & 1;
-      bool ok = true;
+      stp.mark(0);
       if (w == 0) {
         // 1. every wave of every producer has published its partial sums of step k-1
-        ok = poll_ge(gflag + lane, true, tagbase + (unsigned)k) && poll_ge(gflag + 64 + lane, true, tagbase + (unsigned)k);
+        bool ok = false;
+        {
+          const unsigned want = tagbase + (unsigned)k;
+          for (unsigned n = 0; n < SPIN_BUDGET && !ok; ++n) {
+            const unsigned v0 = __hip_atomic_load(gflag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned v1 = __hip_atomic_load(gflag + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = __all((int)(v0 - want) >= 0 && (int)(v1 - want) >= 0);
+          }
+        }
+        stp.mark(1);
         const bool valid = rowok && s < len;
-        float dhs = dha;
-        if (k > 0 && ok && cell_lane) {
+        const float* pf = pfb + (par * 64 + lane) * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pf);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(pf + 4);
+        float dhs = o.z;
+        if (k > 0 && ok && lane_ok) {
           const float* src = gpx + ((size_t)(((k - 1) & 1) * 32 + member) * 32) * 64 + lane;
           float pv[32];
 #define NASR_LD8(g8)                                                                                               \
@@ -374,34 +508,39 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
           for (int p = 0; p < 32; p += 4) { s0 += pv[p]; s1 += pv[p + 1]; s2 += pv[p + 2]; s3 += pv[p + 3]; }
           dhs += (s0 + s1) + (s2 + s3);
         }
+        stp.mark(2);
         // 2. gate derivatives of this CU's cells
-        float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 dg = (f32x4){0.f, 0.f, 0.f, 0.f};
         float dcn = 0.f;
         if (valid) {
-          const float tc = ptanh(cc);
+          const float tc = ptanh(o.x);
           const float dct = dc + dhs * a.w * (1.f - tc * tc);
           dg.x = dct * a.y * a.x * (1.f - a.x);
           dg.y = dct * a.x * (1.f - a.y * a.y);
-          dg.z = dct * cpv * a.z * (1.f - a.z);
+          dg.z = dct * (s > 0 ? o.y : 0.f) * a.z * (1.f - a.z);
           dg.w = dhs * tc * a.w * (1.f - a.w);
           dcn = dct * a.z;
         }
         dc = dcn;
-        if (cell_lane) {   // A image: adg[par][c = 4u+g][utterance q]
+        if (lane_ok) {   // A image: adg[par][c = 4u+g][utterance q]
           float* ad = adg + par * 256 + 16 * u + q;
           ad[0] = dg.x; ad[4] = dg.y; ad[8] = dg.z; ad[12] = dg.w;
         }
-        if (rowok) {       // frame-indexed dG for the weight-gradient GEMMs (zero at masked frames)
-          const size_t row = valid ? (size_t)(d ? (len - 1 - s) : s) * Bp + b : (size_t)s * Bp + b;
-          *reinterpret_cast<float4*>(dgbuf + row * DN + d * N4 + 4 * j) = dg;
-        }
-        a = make_float4(0.f, 0.f, 0.f, 0.f); cc = 0.f; cpv = 0.f; dha = 0.f;
-        if (s > 0) prefetch(s - 1);
         if (!ok) info[2 + par] = 1;
+        stp.mark(3);
+      } else if (w == 4) {
+        if (k + 1 < T) hand_over(k + 1);     // loaded during the previous step's MFMA phase
       }
       __syncthreads();
+      stp.mark(4);
       if (info[2 + par]) { aborted = true; break; }
-      // 3. partial[utt][k'] = sum_c dG[utt][c] * U[k'][c] for this wave's output units, all 4 waves
+      if (w == 4) {
+        // memory wave, while the others are in their MFMA phase: dG of this step out, operands of step k+2 in
+        if (k + 2 < T) prefetch(T - 3 - k);    // loads first: their wait must not sit behind the store's acknowledgement
+        store_dg(k);
+        continue;
+      }
+      // 3. partial[utt][k'] = sum_c dG[utt][c] * U[k'][c] for this wave's output units, waves 0-3
       float av[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) av[v] = (64 * v + lane < 4 * NC) ? adg[par * 256 + 64 * v + lane] : 0.f;
@@ -415,22 +554,26 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_bwd_kernel(
           acc[og][c & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c / 16], wreg[og * NC + c], acc[og][c & 1], 4, c % 16, 0);
         });
       });
-      // 4. hand the partial rows to their consumers: unit k' -> consumer k'/NU, cell lane 16*utt + k'%NU
+      // 4. hand the partial rows to their consumers: unit k' -> consumer k'/NU, row element 4*(k'%NU) + utt
 #pragma unroll
       for (int og = 0; og < NOG; ++og) {
         const f32x4 sum = acc[og][0] + acc[og][1];
         const int kl = og * 64 + lane;
         if (kl < KW) {
           const int kk = w * KW + kl;
-          float* dst = gpx + ((size_t)((par * 32 + kk / NU) * 32) + member) * 64 + (kk % NU);
-          dst[0] = sum[0]; dst[16] = sum[1]; dst[32] = sum[2]; dst[48] = sum[3];
+          float* dst = gpx + ((size_t)((par * 32 + kk / NU) * 32) + member) * 64 + 4 * (kk % NU);
+          *reinterpret_cast<f32x4*>(dst) = sum;
         }
       }
+      stp.mark(5);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stp.mark(6);
       if (lane == 0) *(ctl->flags + xcc * 128 + member * 4 + w) = tagbase + (unsigned)k + 1u;
     }
     if (aborted) break;
+    __syncthreads();                  // pfb / adg are reused by the next round
   }
+  stp.flush(ctl);
   if (aborted && tid == 0) raise_error(ctl, sticky, 1u);
 }
 
@@ -474,7 +617,7 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates,
                              hipStream_t st) {
   const PersistGeom gm = make_geom(dm);
   (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
-  dim3 grid(256), block(256);
+  dim3 grid(256), block(320);
 #define NASR_PF(NUV)                                                                                                  \
   hipLaunchKernelGGL((lstm_persist_fwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upf, gates, cbuf, out, seq_len, \
                      xch, ctl, sticky, gm, forget_bias)
@@ -492,7 +635,7 @@ void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* 
                              hipStream_t st) {
   const PersistGeom gm = make_geom(dm);
   (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
-  dim3 grid(256), block(256);
+  dim3 grid(256), block(320);
 #define NASR_PB(NUV)                                                                                                   \
   hipLaunchKernelGGL((lstm_persist_bwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upb, gates, dgbuf, cbuf, dout, \
                      seq_len, xch, ctl, sticky, gm)

@@ -101,6 +101,12 @@ int main(int argc, char** argv) {
     printf("forward : per-step %.3f us/step   persistent %.3f us/step (%.3f ms)   error word %u  xcc", fstep * 1000 / T, ms * 1000 / T, ms, hc.error);
     for (int i = 0; i < 8; ++i) printf(" %u", hc.xcc_count[i]);
     printf("\n");
+    if (hc.pad[0] | hc.pad[1]) {
+      printf("   wave 0 cycles/step: loop-top %.0f  poll %.0f  payload %.0f  mfma %.0f  barrier %.0f  cell %.0f  store-ack %.0f\n", hc.pad[0] / (double)T,
+             hc.pad[1] / (double)T, hc.pad[2] / (double)T, hc.pad[3] / (double)T, hc.pad[4] / (double)T, hc.pad[5] / (double)T, hc.pad[6] / (double)T);
+      printf("   barrier arrival after wave 0 (cycles): w1 %.0f  w2 %.0f  w3 %.0f  mem %.0f\n", (int)hc.pad[7] / (double)T, (int)hc.pad[8] / (double)T,
+             (int)hc.pad[9] / (double)T, (int)hc.pad[10] / (double)T);
+    }
     if (hc.error) return 1;
     // ---- backward, per-step (on the per-step forward's buffers)
     CK(hipMemsetAsync(par, 0, ps * 4, st)); CK(hipMemsetAsync(dcs, 0, hs * 4, st));
@@ -118,6 +124,11 @@ int main(int argc, char** argv) {
     CK(hipGetLastError());
     CK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
     printf("backward: per-step %.3f us/step   persistent %.3f us/step (%.3f ms)   error word %u\n", bstep * 1000 / T, ms * 1000 / T, ms, hc.error);
+    if (hc.pad[0] | hc.pad[1]) {
+      printf("   wave 0 cycles/step: tail+prefetch %.0f  poll %.0f  partial loads+sum %.0f  cell bwd %.0f  barrier %.0f  mfma+stores %.0f  store-ack %.0f\n",
+             hc.pad[0] / (double)T, hc.pad[1] / (double)T, hc.pad[2] / (double)T, hc.pad[3] / (double)T, hc.pad[4] / (double)T, hc.pad[5] / (double)T,
+             hc.pad[6] / (double)T);
+    }
     if (hc.error) return 1;
   }
   double ma;
