@@ -46,6 +46,28 @@ struct GemmNTDesc {
 void launch_gemm_nt(const GemmNTDesc& g, hipStream_t st);
 void launch_transpose(const float* in, float* out, int R, int C, int ld_in, int ld_out, hipStream_t st);
 
+// ---- fp32-accurate GEMM from pre-split, pre-tiled bf16 operands (gemm_tp.hip): C[M,N] = A[M,K] * B[N,K]^T (+bias) ----
+// A "tiled planes" (TP) operand holds the three bf16 parts of an fp32 matrix [rows][K] as 1 KiB tiles
+// TP[row/32][k/16][part][32 rows x 16 k]; tp_bytes() sizes it, launch_tp_split() fills it from fp32 (element (row,k) =
+// src[row*ld + k], or src[k*ld + row] when `transposed`).
+size_t tp_bytes(int rows, int K);
+void launch_tp_split(const float* src, unsigned char* tp, int rows, int K, int ld, bool transposed, hipStream_t st);
+struct GemmTPDesc {
+  const unsigned char* A;   // TP of [>= M rows][K_A], starting at the first row block used
+  const unsigned char* B;   // TP of [>= N rows][K_B]
+  float* C;
+  int M, N, K;              // M, N multiples of 4 (row blocks past M / N read as zero), K = contraction length
+  int nkbA, nkbB;           // k-blocks per row block in A / B: ceil(K_A/16), ceil(K_B/16)
+  int ldc;
+  int a_kshift;             // multiple of 16: A is read at k + a_kshift, zero outside [0, K_A)
+  const float* bias;        // per-n, only with split_k == 1
+  int split_k;              // > 1: partial slabs + reduction; needs ldc == N and no bias
+  float* slabs;             // split_k * M * N floats
+};
+hipError_t gemm_tp_prepare();    // once per process: raise the kernel's dynamic-LDS limit
+int gemm_tp_pick_split(int M, int N, int K);
+void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st);
+
 // ---- LSTM recurrence (lstm.hip) ----
 struct LstmDims {
   int T, B, Bp, H, Hp, D;   // D directions

@@ -83,6 +83,12 @@ struct nasr_ctx {
   hipEvent_t ev_fork = nullptr;
   std::vector<hipEvent_t> ev_done, ev_dx;   // [layer * PIPE_MAX_CHUNKS + chunk]
   bool gemm_bf16 = true;               // bulk GEMMs on the bf16 matrix cores (fp32-accurate 3-way split), NASR_GEMM=f32 disables
+  // NASR_GEMM=tp (default): the same arithmetic from operands split ONCE into tiled bf16 planes (gemm_tp.hip);
+  // NASR_GEMM=bf16 keeps the split-while-staging kernel (gemm_bf16.hip), NASR_GEMM=f32 the f32-MFMA kernel (gemm.hip).
+  bool gemm_tp = true;
+  unsigned char* WfTP = nullptr;       // per layer TP of Wx^T [D*N4][Ip]: B operand of the input GEMM
+  unsigned char* WbTP = nullptr;       // per layer (l >= 1) TP of Wx [Ip][D*N4]: B operand of the input-gradient GEMM
+  std::vector<size_t> off_wftp, off_wbtp;
   // Persistent recurrence (lstm_persist.hip): one launch per layer pass instead of T step launches.  Needs the full
   // 8 XCD x 32 CU chip and Hp in {64,128,256,512}; NASR_PERSIST=0 keeps the per-step kernels.
   bool persist = false;
@@ -117,6 +123,7 @@ struct nasr_ctx {
   int64_t frames = 0;
   std::vector<int32_t> h_seq;
 
+  DevBuf XTP, X0TTP, OTTP0, OTTP1, GTP, GTTP;   // tiled-plane copies of activations / dG (gemm_tp)
   DevBuf X0T, outT0, outT1, dGT, feats_bm, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
       rowmap, slabs, csws, amax, ids, lens, stage;
   std::vector<DevBuf> gates, outb, cbuf;
@@ -314,7 +321,13 @@ int repack(nasr_ctx* h) {
       launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
       if (h->persist) launch_repack_persist(h->P + h->off_u[k], h->Upf + k * h->imf, h->Upb + k * h->imb, h->Hp, h->st);
     }
-  if (h->gemm_bf16)
+  if (h->gemm_tp) {
+    for (int l = 0; l < h->L; ++l) {
+      launch_tp_split(h->P + h->off_wx[l], h->WfTP + h->off_wftp[l], h->D * h->N4, h->Ip[l], h->D * h->N4, true, h->st);
+      if (l > 0)
+        launch_tp_split(h->P + h->off_wx[l], h->WbTP + h->off_wbtp[l], h->Ip[l], h->D * h->N4, h->D * h->N4, false, h->st);
+    }
+  } else if (h->gemm_bf16)
     for (int l = 0; l < h->L; ++l)
       launch_transpose(h->P + h->off_wx[l], h->WxT + h->off_wxt[l], h->Ip[l], h->D * h->N4, h->D * h->N4, h->Ip[l],
                        h->st);
@@ -357,7 +370,16 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
     ok &= h->dcstateL[i].ensure((size_t)2 * D * Bp * Hp * 4, &grew);
     ok &= h->dgL[i].ensure(R * D * N4 * 4, &grew);
   }
-  if (h->gemm_bf16) {
+  if (h->gemm_tp) {
+    int ipmax = h->Fp;
+    for (int l = 0; l < h->L; ++l) ipmax = std::max(ipmax, h->Ip[l]);
+    ok &= h->XTP.ensure(tp_bytes((int)R, ipmax), &grew);
+    ok &= h->X0TTP.ensure(tp_bytes(h->Fp, (int)R), &grew);
+    ok &= h->OTTP0.ensure(tp_bytes(D * Hp, (int)R), &grew);
+    ok &= h->OTTP1.ensure(tp_bytes(D * Hp, (int)R), &grew);
+    ok &= h->GTP.ensure(tp_bytes((int)R, D * N4), &grew);
+    ok &= h->GTTP.ensure(tp_bytes(D * N4, (int)R), &grew);
+  } else if (h->gemm_bf16) {
     ok &= h->X0T.ensure(R * h->Fp * 4, &grew);
     ok &= h->outT0.ensure(R * D * Hp * 4, &grew);
     ok &= h->outT1.ensure(R * D * Hp * 4, &grew);
@@ -483,7 +505,10 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
                             h->X0.as<float>(), B, Bp, T, ctx, ncep, h->Fp, h->st);
     else
       launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
-    if (h->gemm_bf16 && labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
+    if (h->gemm_tp) {
+      if (labels)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
+        launch_tp_split(h->X0.as<float>(), h->X0TTP.as<unsigned char>(), h->Fp, T * Bp, h->Fp, true, h->st);
+    } else if (h->gemm_bf16 && labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
       launch_transpose(h->X0.as<float>(), h->X0T.as<float>(), T * Bp, h->Fp, h->Fp, T * Bp, h->st);
     HIPCHK(h, hipGetLastError());
   }
@@ -575,7 +600,14 @@ void gemm_xproj(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
   const int D = h->D, N4 = h->N4, Ip = h->Ip[l];
   const float* Xl = (l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>()) + (size_t)r0 * Ip;
   float* C = h->gates[l].as<float>() + (size_t)r0 * D * N4;
-  if (h->gemm_bf16) {
+  if (h->gemm_tp) {
+    launch_tp_split(Xl, h->XTP.as<unsigned char>(), nr, Ip, Ip, false, st);
+    GemmTPDesc g{};
+    g.A = h->XTP.as<unsigned char>(); g.B = h->WfTP + h->off_wftp[l]; g.C = C;
+    g.M = nr; g.N = D * N4; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * N4;
+    g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+    launch_gemm_tp(g, st);
+  } else if (h->gemm_bf16) {
     GemmNTDesc g{};
     g.A = Xl; g.B = h->WxT + h->off_wxt[l]; g.C = C;
     g.M = nr; g.N = D * N4; g.K = Ip; g.lda = Ip; g.ldb = Ip; g.ldc = D * N4;
@@ -595,7 +627,16 @@ void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
   const int D = h->D, N4 = h->N4, Hp = h->Hp;
   const float* A = dg_of(h, l) + (size_t)r0 * D * N4;
   float* C = dout_of(h, l - 1) + (size_t)r0 * D * Hp;
-  if (h->gemm_bf16) {
+  if (h->gemm_tp) {
+    launch_tp_split(A, h->GTP.as<unsigned char>(), nr, D * N4, D * N4, false, st);
+    GemmTPDesc g{};
+    g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
+    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * Hp;
+    g.split_k = g.ldc == g.N ? gemm_tp_pick_split(g.M, g.N, g.K) : 1;
+    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+    if (g.split_k > 1 && !g.slabs) g.split_k = 1;
+    launch_gemm_tp(g, st);
+  } else if (h->gemm_bf16) {
     GemmNTDesc g{};
     g.A = A; g.B = h->P + h->off_wx[l]; g.C = C;
     g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp; g.split_k = 1;
@@ -706,7 +747,38 @@ int weight_grads(nasr_ctx* h, int l) {
   float* dG = dg_of(h, l);
   hipStream_t ws = h->st;
   const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
-  if (h->gemm_bf16) {
+  if (h->gemm_tp) {
+    // tiled-plane copies with the frame index as contraction index (K = R)
+    unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
+    unsigned char* GT = h->GTTP.as<unsigned char>();
+    const int nkb = (R + 15) / 16;
+    launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);
+    if (l == h->L - 1) launch_tp_split(h->outb[l].as<float>(), tO[l & 1], D * Hp, R, D * Hp, true, ws);
+    if (l > 0) launch_tp_split(h->outb[l - 1].as<float>(), tO[(l - 1) & 1], D * Hp, R, D * Hp, true, ws);
+    {  // dWx = X^T dG
+      GemmTPDesc g{};
+      g.A = l == 0 ? h->X0TTP.as<unsigned char>() : tO[(l - 1) & 1];
+      g.B = GT; g.C = h->G + h->off_wx[l];
+      g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
+      g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm_tp(g, ws);
+    }
+    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
+    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
+      GemmTPDesc g{};
+      g.A = tO[l & 1] + (size_t)(d * Hp / 32) * nkb * 3 * 1024;
+      g.B = GT + (size_t)(d * N4 / 32) * nkb * 3 * 1024;
+      g.C = h->G + h->off_u[(size_t)l * D + d];
+      g.M = Hp; g.N = N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
+      g.a_kshift = d == 0 ? -Bp : Bp;
+      g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+      launch_gemm_tp(g, ws);
+    }
+  } else if (h->gemm_bf16) {
     // K-contiguous copies of the operands whose contraction index is the row (time) index
     float* tOut[2] = {h->outT0.as<float>(), h->outT1.as<float>()};
     launch_transpose(dG, h->dGT.as<float>(), R, D * N4, D * N4, R, ws);
@@ -929,13 +1001,30 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   {
     const char* e = getenv("NASR_GEMM");
     h->gemm_bf16 = !(e && std::string(e) == "f32");
+    // the tiled-plane copies of activations are single scratch buffers: not for the multi-stream layer pipeline
+    const char* ep = getenv("NASR_PIPE");
+    const char* es = getenv("NASR_PERSIST");
+    const bool persist_cand = !(es && es[0] == '0') && persist_supported(h->Hp) && prop.multiProcessorCount == 256;
+    const bool pipe_cand = h->D == 1 && h->L > 1 && !(ep && ep[0] == '0') && !persist_cand;
+    h->gemm_tp = h->gemm_bf16 && !(e && std::string(e) == "bf16") && !pipe_cand;
+    if (h->gemm_tp) {
+      size_t of = 0, ob = 0;
+      h->off_wftp.resize(h->L); h->off_wbtp.resize(h->L);
+      for (int l = 0; l < h->L; ++l) {
+        h->off_wftp[l] = of; of += tp_bytes(h->D * h->N4, h->Ip[l]);
+        h->off_wbtp[l] = ob; if (l > 0) ob += tp_bytes(h->Ip[l], h->D * h->N4);
+      }
+      if (gemm_tp_prepare() != hipSuccess || hipMalloc(&h->WfTP, of) != hipSuccess ||
+          hipMalloc(&h->WbTP, std::max<size_t>(ob, 1024)) != hipSuccess)
+        return bail(NASR_ERR_HIP, "hipMalloc of the tiled weight planes failed");
+    }
     int64_t o = 0;
     h->off_wxt.resize(h->L);
     for (int l = 0; l < h->L; ++l) {
       h->off_wxt[l] = o;
       o += (int64_t)h->Ip[l] * h->D * h->N4;
     }
-    if (h->gemm_bf16 && hipMalloc(&h->WxT, (size_t)o * 4) != hipSuccess)
+    if (h->gemm_bf16 && !h->gemm_tp && hipMalloc(&h->WxT, (size_t)o * 4) != hipSuccess)
       return bail(NASR_ERR_HIP, "hipMalloc of transposed weights failed");
   }
   const size_t nb = (size_t)h->np_int * 4;
@@ -1043,8 +1132,11 @@ int nasr_destroy(nasr_handle h) {
   drop_graphs(h);
   for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub, h->WxT, h->Upf, h->Upb, h->xch})
     if (p) (void)hipFree(p);
+  if (h->WfTP) (void)hipFree(h->WfTP);
+  if (h->WbTP) (void)hipFree(h->WbTP);
   if (h->pctl) (void)hipFree(h->pctl);
   if (h->perr) (void)hipHostFree(h->perr);
+  for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->OTTP0, &h->OTTP1, &h->GTP, &h->GTTP}) b->release();
   for (DevBuf* b : {&h->feats_bm, &h->X0, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})

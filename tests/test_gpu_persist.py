@@ -1,0 +1,117 @@
+"""GPU: the persistent recurrence (neuralasr_amd/csrc/lstm_persist.hip: one launch per layer pass, one XCD per
+(direction, utterance slice)) against the fp64 oracle AND against the per-timestep kernels of lstm.hip on the same
+inputs, through the C ABI.  Same tolerances as tests/test_gpu_parity.py.  The shapes exercise every
+kernel instantiation (Hp 64 / 128 / 256 / 512), several rounds over the batch (B > 16 bidirectional), partly filled
+utterance slices, ragged lengths with T far above the shortest utterance, and the per-step fallback for hidden sizes the
+persistent kernels do not cover."""
+import numpy as np
+import pytest
+
+from oracle import nasr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(spec, lr=1e-3):
+    from neuralasr_amd.engine import Engine
+    return Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
+                  forget_bias=spec.forget_bias, learning_rate=lr)
+
+
+def rand_params(spec, seed):
+    rs = np.random.RandomState(seed)
+    return [p + 0.05 * rs.randn(*p.shape) for p in O.init_params(spec, seed=seed)]
+
+
+CASES = [
+    # spec, B, T                                                   Hp   what it exercises
+    (O.ModelSpec(14, 50, 1, True, 'stack_reshape', 8), 5, 37),    # 64   NU 2, partly filled slices (B 5 of Bp 16)
+    (O.ModelSpec(13, 128, 1, False, 'none', 6), 4, 60),           # 128  config 1 of BASELINE.json (lstm_ctc_net 1x128)
+    (O.ModelSpec(20, 200, 2, True, 'concat', 11), 19, 24),        # 256  NU 8, 2 rounds (Bp 32), 2 layers
+    (O.ModelSpec(26, 500, 1, True, 'stack_reshape', 29), 16, 48),  # 512  the literal BiLstmCTCNet width
+    (O.ModelSpec(12, 300, 1, False, 'none', 7), 40, 18),          # 512 (padded from 300) uni, Bp 48: 2 rounds of 8 x 4
+    (O.ModelSpec(12, 120, 3, False, 'none', 9), 3, 90),           # 128  3-layer uni stack, B 3
+]
+
+
+def case_id(c):
+    s, B, T = c
+    return f"H{s.hidden}L{s.num_layers}{'bi' if s.bidirectional else 'uni'}-B{B}T{T}"
+
+
+@pytest.mark.parametrize("case", CASES, ids=case_id)
+def test_persistent_matches_oracle_and_per_step_kernels(case):
+    spec, B, T = case
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=7 * B + T, var_len=True, Lmin=1, Lmax=max(1, T // 5))
+    seq_len[0] = max(int(label_len[0]) * 2 + 1, T // 3)            # one short utterance: many masked steps
+    feats[0, seq_len[0]:] = 0.0
+    params = rand_params(spec, 5)
+    e = make_engine(spec)
+    assert e.recurrence_mode == 'persistent', 'MI355X (8 XCDs x 32 CUs) must pass the census at create time'
+    e.set_params(O.flatten(params))
+
+    loss_o, nll_o, grads_o, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+    logits_p = e.forward(feats, seq_len)
+    np.testing.assert_allclose(logits_p, logits_o, atol=1e-4)
+    loss_p, nll_p, grads_p = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert loss_p == pytest.approx(loss_o, rel=2e-5)
+    np.testing.assert_allclose(nll_p, nll_o, rtol=2e-5)
+    gflat_o = O.flatten(grads_o)
+    scale = np.linalg.norm(gflat_o)
+    for (name, off, r, c), g_o in zip(e.tensors(), grads_o):
+        g = grads_p[off:off + r * c].reshape(g_o.shape)
+        assert np.linalg.norm(g - g_o) <= 1e-4 * np.linalg.norm(g_o) + 1e-6 * scale, name
+
+    # the same step through the per-timestep kernels: the two HIP paths agree far inside the oracle tolerance
+    e.set_recurrence_mode(False)
+    assert e.recurrence_mode == 'per-step'
+    logits_s = e.forward(feats, seq_len)
+    loss_s, nll_s, grads_s = e.loss_and_grads(feats, seq_len, labels, label_len)
+    np.testing.assert_allclose(logits_p, logits_s, atol=2e-5)
+    assert loss_p == pytest.approx(loss_s, rel=2e-6)
+    assert np.linalg.norm(grads_p - grads_s) <= 2e-5 * np.linalg.norm(grads_s)
+    # identical greedy decodes (north_star) in both modes
+    hyp_s = e.greedy_decode(feats, seq_len)
+    e.set_recurrence_mode(True)
+    assert e.recurrence_mode == 'persistent'
+    hyp_p = e.greedy_decode(feats, seq_len)
+    assert hyp_p == hyp_s
+    e.close()
+
+
+def test_training_steps_agree_between_modes():
+    """Three Adam steps in each mode from the same start: parameters stay together (the operand images of the
+    persistent kernels are rebuilt after every update)."""
+    spec = O.ModelSpec(16, 96, 2, True, 'concat', 10)
+    B, T = 8, 30
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=11, var_len=True, Lmin=1, Lmax=6)
+    start = O.flatten(rand_params(spec, 2)).astype(np.float32)
+    out = []
+    for persistent in (True, False):
+        e = make_engine(spec, lr=1e-3)
+        e.set_recurrence_mode(persistent)
+        e.set_params(start)
+        losses = [e.train_step(feats, seq_len, labels, label_len) for _ in range(3)]
+        out.append((np.array(losses), e.get_params()))
+        e.close()
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=5e-6)
+    assert out[0][0][-1] < out[0][0][0]
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=2e-6)
+
+
+def test_unsupported_width_uses_per_step_kernels():
+    """Hp = 704 (22 units per CU) has no persistent instantiation: the engine reports and uses the per-step kernels,
+    and asking for the persistent ones is an error, not a silent fallback."""
+    spec = O.ModelSpec(10, 700, 1, True, 'concat', 5)
+    B, T = 2, 9
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=3, Lmin=1, Lmax=3)
+    params = rand_params(spec, 1)
+    e = make_engine(spec)
+    assert e.recurrence_mode == 'per-step'
+    with pytest.raises(RuntimeError):
+        e.set_recurrence_mode(True)
+    e.set_params(O.flatten(params))
+    loss_o, _, _, _ = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+    loss, _, _ = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert loss == pytest.approx(loss_o, rel=2e-5)
+    e.close()

@@ -2,6 +2,8 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DNASR_GEMM_BK=..] tools/gemmbench.hip -o tools/sb_gemm
 #include "../neuralasr_amd/csrc/gemm.hip"
 #include "../neuralasr_amd/csrc/gemm_bf16.hip"
+#include "../neuralasr_amd/csrc/gemm_tp.hip"
+#include "../neuralasr_amd/csrc/optim.hip"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -70,6 +72,53 @@ int main() {
     }
     printf("bf16x6 %s split %d : %.3f ms  %.1f TF-equiv   rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, c.split, best,
            2.0 * c.M * c.N * c.K / best / 1e9, sqrt(num / den), mx);
+  }
+  // ---- tiled-plane kernel (gemm_tp.hip): split passes + GEMM, numerics vs the fp32 kernel
+  CK(gemm_tp_prepare());
+  unsigned char *TA, *TB;
+  CK(hipMalloc(&TA, tp_bytes(R, 4096))); CK(hipMalloc(&TB, tp_bytes(4096, R)));
+  for (auto& c : nts) {
+    if ((size_t)c.M * c.K > c.a_elems || (size_t)c.N * c.K > c.b_elems) continue;
+    const int split = gemm_tp_pick_split(c.M, c.N, c.K);
+    GemmDesc f{}; f.A = c.A; f.B = c.B; f.C = O2; f.M = c.M; f.N = c.N; f.K = c.K; f.lda = c.K; f.ldb = c.K; f.ldc = c.N;
+    f.b_col = true; f.a_rows = c.M; f.split_k = 1;
+    launch_gemm(f, st);
+    float tsplit = 1e9f;
+    for (int i = 0; i < 3; ++i) {
+      CK(hipEventRecord(a, st));
+      launch_tp_split(c.A, TA, c.M, c.K, c.K, false, st); launch_tp_split(c.B, TB, c.N, c.K, c.K, false, st);
+      CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); tsplit = ms < tsplit ? ms : tsplit;
+    }
+    GemmTPDesc g{}; g.A = TA; g.B = TB; g.C = O; g.M = c.M; g.N = c.N; g.K = c.K; g.nkbA = (c.K + 15) / 16; g.nkbB = g.nkbA; g.ldc = c.N;
+    g.split_k = split; g.slabs = slabs;
+    if ((size_t)split * c.M * c.N > (size_t)8 * 1024 * 4096) { printf("slabs too small\n"); continue; }
+    CK(hipMemset(O, 0xff, (size_t)c.M * c.N * 4));
+    launch_gemm_tp(g, st); CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+    std::vector<float> h1((size_t)c.M * c.N), h2((size_t)c.M * c.N);
+    CK(hipMemcpy(h1.data(), O, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), O2, h2.size() * 4, hipMemcpyDeviceToHost));
+    double num = 0, den = 0, mx = 0;
+    for (size_t i = 0; i < h1.size(); ++i) { double d = (double)h1[i] - h2[i]; num += d * d; den += (double)h2[i] * h2[i]; if (!(fabs(d) <= mx)) mx = fabs(d); }
+    float best = 1e9f;
+    for (int i = 0; i < 10; ++i) {
+      CK(hipEventRecord(a, st)); launch_gemm_tp(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+    }
+    printf("tp     %s split %d : %.3f ms  %.1f TF-equiv (+ %.3f ms to split both operands)  rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, split, best,
+           2.0 * c.M * c.N * c.K / best / 1e9, tsplit, sqrt(num / den), mx);
+  }
+  // transposed split: TP from a [K][rows] source must equal TP from the explicit transpose
+  {
+    launch_transpose(G, O2, R, 4096, 4096, R, st);                 // O2 = G^T [4096][R]
+    launch_tp_split(O2, TB, 4096, R, R, false, st);
+    unsigned char* TC; CK(hipMalloc(&TC, tp_bytes(4096, R)));
+    launch_tp_split(G, TC, 4096, R, 4096, true, st);
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned char> u1(tp_bytes(4096, R)), u2(tp_bytes(4096, R));
+    CK(hipMemcpy(u1.data(), TB, u1.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(u2.data(), TC, u2.size(), hipMemcpyDeviceToHost));
+    size_t bad = 0; for (size_t i = 0; i < u1.size(); ++i) bad += u1[i] != u2[i];
+    float best = 1e9f; for (int i = 0; i < 5; ++i) { CK(hipEventRecord(a, st)); launch_tp_split(G, TC, 4096, R, 4096, true, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; }
+    printf("transposed split 8000x4096 -> TP[4096][8000]: %zu differing bytes vs transpose+split, %.3f ms\n", bad, best);
   }
   // transpose
   { float best = 1e9f; for (int i = 0; i < 5; ++i) { CK(hipEventRecord(a, st)); launch_transpose(G, O, R, 4096, 4096, R, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; }
