@@ -48,15 +48,29 @@ class ModelSpec:
     merge: str            # 'stack_reshape' | 'concat' | 'none' (unidirectional)
     num_classes: int
     forget_bias: float = 1.0
+    # DeepSpeech-style dense stages (networks/deepspeech.py:43-121): clipped-ReLU layers with dropout before the
+    # LSTM stack (`pre` = their widths) and one between the stack and the logits (`post`, 0 = none).
+    pre: tuple = ()
+    post: int = 0
+    relu_clip: float = 20.0
+    dropout: tuple = ()          # drop probability per dense layer: len(pre) entries, then one for `post`
 
     @property
     def dirs(self):
         return 2 if self.bidirectional else 1
 
+    @property
+    def deepspeech(self):
+        return bool(self.pre) or self.post > 0
+
     def layer_input(self, l):
         if l == 0:
-            return self.feature_size
+            return self.pre[-1] if self.pre else self.feature_size
         return self.hidden * self.dirs
+
+    def drop_p(self, i):
+        """drop probability of dense layer i (0..len(pre)-1 = pre layers, len(pre) = post layer)."""
+        return float(self.dropout[i]) if i < len(self.dropout) else 0.0
 
     @property
     def proj_in(self):
@@ -76,6 +90,13 @@ class ModelSpec:
         (kernel, bias); then W, b.  kernel rows are [input ; h] (Appendix A.1)."""
         H = self.hidden
         out = []
+        if self.deepspeech:
+            # networks/deepspeech.py creates b_i before h_i: b1,h1,b2,h2,b3,h3, fw/bw cells, b5,h5,b6,h6
+            w_in = self.feature_size
+            for i, w in enumerate(self.pre):
+                out.append((f'b{i + 1}', (w,)))
+                out.append((f'h{i + 1}', (w_in, w)))
+                w_in = w
         for l in range(self.num_layers):
             I = self.layer_input(l)
             if self.bidirectional:
@@ -85,6 +106,15 @@ class ModelSpec:
             else:
                 out.append((f'l{l}/kernel', (I + H, 4 * H)))
                 out.append((f'l{l}/bias', (4 * H,)))
+        if self.deepspeech:
+            w_in = self.proj_in
+            if self.post:
+                out.append(('b5', (self.post,)))
+                out.append(('h5', (w_in, self.post)))
+                w_in = self.post
+            out.append(('b6', (self.num_classes,)))
+            out.append(('h6', (w_in, self.num_classes)))
+            return out
         out.append(('W', (self.proj_in, self.num_classes)))
         out.append(('b', (self.num_classes,)))
         return out
@@ -103,6 +133,11 @@ def init_params(spec: ModelSpec, seed=1, dtype=np.float64):
         if name.endswith('kernel'):
             lim = np.sqrt(6.0 / (shp[0] + shp[1]))
             params.append(rs.uniform(-lim, lim, size=shp).astype(dtype))
+        elif name[0] in 'hb' and name[1:].isdigit():       # DeepSpeech dense stages: N(0, 0.046875) (deepspeech.py:25)
+            if name in ('h1', 'h6'):                        # xavier-normal (deepspeech.py:47,120)
+                params.append((rs.randn(*shp) * np.sqrt(2.0 / (shp[0] + shp[1]))).astype(dtype))
+            else:
+                params.append((rs.randn(*shp) * 0.046875).astype(dtype))
         elif name == 'W':
             params.append((rs.randn(*shp) * np.sqrt(2.0 / (shp[0] + shp[1]))).astype(dtype))
         else:
@@ -468,8 +503,44 @@ def label_error_rate(hyps, labels, label_len):
     return float(np.mean(v))
 
 
+# --------------------------------------------------------------------------- dense stages (DeepSpeech)
+def dropout_mask(seed, counter, layer, T, B, W, p):
+    """Keep-mask [T,B,W] of tf.nn.dropout(x, 1-p) (networks/deepspeech.py:50,59,68,113).  TF's random stream cannot be
+    reproduced, so the mask is DEFINED by a counter-based hash both sides compute (oracle here, HIP in
+    neuralasr_amd/csrc/dense.hip): element (t,b,j) of dense layer `layer` on forward pass number `counter` is kept iff
+    lowbias32(idx ^ key) >> 8 >= floor(p * 2^24), idx = (t*B + b)*W + j."""
+    if p <= 0.0:
+        return np.ones((T, B, W), bool)
+    idx = np.arange(T * B * W, dtype=np.uint64).astype(np.uint32)
+    key = np.uint32((int(seed) + 0x9E3779B9 * (int(layer) + 1) + 0x85EBCA6B * int(counter)) & 0xFFFFFFFF)
+    x = idx ^ key
+    x ^= x >> np.uint32(16)
+    x = (x.astype(np.uint64) * 0x7FEB352D & 0xFFFFFFFF).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x.astype(np.uint64) * 0x846CA68B & 0xFFFFFFFF).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    thr = np.uint32(int(np.floor(p * (1 << 24))))
+    return ((x >> np.uint32(8)) >= thr).reshape(T, B, W)
+
+
+def dense_forward(x, W, b, clip, mask, p):
+    """min(relu(x W + b), clip) then tf.nn.dropout: kept elements scaled by 1/(1-p).  x [..., I] -> [..., O]."""
+    z = x @ W + b
+    a = np.minimum(np.maximum(z, 0.0), clip)
+    return a * mask / (1.0 - p), z
+
+
+def dense_backward(dy, x, z, W, clip, mask, p):
+    da = dy * mask / (1.0 - p)
+    dz = da * ((z > 0.0) & (z < clip))
+    x2, dz2 = x.reshape(-1, x.shape[-1]), dz.reshape(-1, dz.shape[-1])
+    return (dz2 @ W.T).reshape(x.shape), x2.T @ dz2, dz2.sum(0)
+
+
 # --------------------------------------------------------------------------- network
-def network_forward(spec: ModelSpec, params, feats, seq_len):
+def network_forward(spec: ModelSpec, params, feats, seq_len, drop=None):
+    if spec.deepspeech:
+        return _deepspeech_forward(spec, params, feats, seq_len, drop)
     """create_network up to the time-major logits (networks/bilstm_ctc_net.py:17-48,
     networks/lstm_ctc_net.py:17-43).  feats [B,T,F] batch-major -> logits [T',B,C]."""
     feats = np.asarray(feats, np.float64)
@@ -506,9 +577,95 @@ def network_forward(spec: ModelSpec, params, feats, seq_len):
     return logits, dict(caches=caches, flat=flat, B=B, T=T)
 
 
-def network_loss_and_grads(spec: ModelSpec, params, feats, seq_len, labels, label_len):
+def _deepspeech_forward(spec, params, feats, seq_len, drop):
+    """networks/deepspeech.py:35-127: time-major dense stages -> BiLSTM (concat) -> dense -> logits [T,B,C].
+    `drop` = (seed, counter) of the dropout masks, or None for no dropout."""
+    feats = np.asarray(feats, np.float64)
+    B, T, _ = feats.shape
+    p = [np.asarray(q, np.float64) for q in params]
+    x = feats.transpose(1, 0, 2)                      # [T,B,F]
+    pi, dense = 0, []
+
+    def mask_for(i, W):
+        pr = spec.drop_p(i) if drop is not None else 0.0
+        m = dropout_mask(drop[0], drop[1], i, T, B, W, pr) if pr > 0 else np.ones((T, B, W), bool)
+        return m, pr
+    for i, w in enumerate(spec.pre):
+        b_, W_ = p[pi], p[pi + 1]
+        pi += 2
+        m, pr = mask_for(i, w)
+        y, z = dense_forward(x, W_, b_, spec.relu_clip, m, pr)
+        dense.append((x, z, W_, m, pr))
+        x = y
+    xb = x.transpose(1, 0, 2)                         # batch-major for the LSTM helpers
+    caches = []
+    for l in range(spec.num_layers):
+        if spec.bidirectional:
+            of, cf = lstm_dir_forward(xb, seq_len, p[pi], p[pi + 1], spec.forget_bias, False)
+            ob, cb = lstm_dir_forward(xb, seq_len, p[pi + 2], p[pi + 3], spec.forget_bias, True)
+            pi += 4
+            caches.append((cf, cb))
+            xb = np.concatenate([of, ob], 2)
+        else:
+            o, c = lstm_dir_forward(xb, seq_len, p[pi], p[pi + 1], spec.forget_bias, False)
+            pi += 2
+            caches.append((c,))
+            xb = o
+    x = xb.transpose(1, 0, 2)                         # [T,B,proj_in]
+    post = None
+    if spec.post:
+        b_, W_ = p[pi], p[pi + 1]
+        pi += 2
+        m, pr = mask_for(len(spec.pre), spec.post)
+        y, z = dense_forward(x, W_, b_, spec.relu_clip, m, pr)
+        post = (x, z, W_, m, pr)
+        x = y
+    b6, W6 = p[pi], p[pi + 1]
+    logits = x @ W6 + b6                              # [T,B,C], already time-major
+    return logits, dict(caches=caches, dense=dense, post=post, last=x, W6=W6, B=B, T=T, pi_lstm=2 * len(spec.pre))
+
+
+def _deepspeech_loss_and_grads(spec, params, feats, seq_len, labels, label_len, drop):
+    logits, fc = _deepspeech_forward(spec, params, feats, seq_len, drop)
+    B, T = fc['B'], fc['T']
+    H = spec.hidden
+    nll, dlog = ctc_loss_and_grad(logits, labels, label_len, seq_len)
+    loss = float(nll.mean())
+    dlog = dlog / B
+    grads = [None] * len(params)
+    last = fc['last']
+    grads[-1] = last.reshape(-1, last.shape[-1]).T @ dlog.reshape(-1, spec.num_classes)   # h6
+    grads[-2] = dlog.reshape(-1, spec.num_classes).sum(0)                                # b6
+    dx = dlog @ fc['W6'].T
+    pi = len(params) - 2
+    if spec.post:
+        x, z, W_, m, pr = fc['post']
+        dx, dW, db = dense_backward(dx, x, z, W_, spec.relu_clip, m, pr)
+        pi -= 2
+        grads[pi], grads[pi + 1] = db, dW
+    dxb = dx.transpose(1, 0, 2)                        # batch-major [B,T,proj_in]
+    for l in reversed(range(spec.num_layers)):
+        if spec.bidirectional:
+            pi -= 4
+            dxf, grads[pi], grads[pi + 1] = lstm_dir_backward(fc['caches'][l][0], dxb[:, :, :H])
+            dxr, grads[pi + 2], grads[pi + 3] = lstm_dir_backward(fc['caches'][l][1], dxb[:, :, H:])
+            dxb = dxf + dxr
+        else:
+            pi -= 2
+            dxb, grads[pi], grads[pi + 1] = lstm_dir_backward(fc['caches'][l][0], dxb)
+    dx = dxb.transpose(1, 0, 2)
+    for i in reversed(range(len(spec.pre))):
+        x, z, W_, m, pr = fc['dense'][i]
+        dx, dW, db = dense_backward(dx, x, z, W_, spec.relu_clip, m, pr)
+        grads[2 * i], grads[2 * i + 1] = db, dW
+    return loss, nll, grads, logits
+
+
+def network_loss_and_grads(spec: ModelSpec, params, feats, seq_len, labels, label_len, drop=None):
     """loss = reduce_mean(ctc_loss) (networks/tfnetwork.py:59) and d loss / d every variable,
     in TF variable order.  Returns (loss, nll[B], grads list, logits)."""
+    if spec.deepspeech:
+        return _deepspeech_loss_and_grads(spec, params, feats, seq_len, labels, label_len, drop)
     logits, fc = network_forward(spec, params, feats, seq_len)
     B, T = fc['B'], fc['T']
     H, C = spec.hidden, spec.num_classes

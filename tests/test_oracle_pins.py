@@ -260,3 +260,65 @@ def test_sparse_tuple_from_golden():
     assert i.tolist() == [[0, 0], [0, 1], [1, 0]] and i.dtype == np.int64
     assert v.tolist() == [1, 2, 3] and v.dtype == np.int32
     assert s.tolist() == [2, 2] and s.dtype == np.int64
+
+
+# ----------------------------------------------------------------- DeepSpeech dense stages
+def _torch_deepspeech(spec, params, feats, seq_len, labels, label_len, masks):
+    x = torch.tensor(feats, dtype=torch.float64).permute(1, 0, 2)
+    B, T = feats.shape[0], feats.shape[1]
+    pi = 0
+
+    def dense(x, b, W, m, p):
+        a = torch.clamp(torch.relu(x @ W + b), max=spec.relu_clip)
+        return a * torch.tensor(m, dtype=torch.float64) / (1.0 - p)
+    for i in range(len(spec.pre)):
+        x = dense(x, params[pi], params[pi + 1], masks[i], spec.drop_p(i))
+        pi += 2
+    xb = x.permute(1, 0, 2)
+    of = _torch_lstm_dir(xb, seq_len, params[pi], params[pi + 1], spec.forget_bias, False)
+    ob = _torch_lstm_dir(xb, seq_len, params[pi + 2], params[pi + 3], spec.forget_bias, True)
+    pi += 4
+    x = torch.cat([of, ob], 2).permute(1, 0, 2)
+    if spec.post:
+        x = dense(x, params[pi], params[pi + 1], masks[len(spec.pre)], spec.drop_p(len(spec.pre)))
+        pi += 2
+    logits = x @ params[pi + 1] + params[pi]
+    nll = torch.nn.functional.ctc_loss(torch.log_softmax(logits, -1), torch.tensor(labels), torch.tensor(seq_len),
+                                       torch.tensor(label_len), blank=spec.num_classes - 1, reduction='none')
+    return logits, nll.mean()
+
+
+def test_deepspeech_family_matches_torch_autograd():
+    spec = O.ModelSpec(6, 5, 1, True, 'concat', 5, pre=(7, 8, 10), post=9, relu_clip=1.5, dropout=(0.3, 0.2, 0.25, 0.4))
+    names = [n for n, _ in spec.param_shapes()]
+    assert names == ['b1', 'h1', 'b2', 'h2', 'b3', 'h3', 'l0/fw/kernel', 'l0/fw/bias', 'l0/bw/kernel', 'l0/bw/bias',
+                     'b5', 'h5', 'b6', 'h6']                      # creation order of networks/deepspeech.py
+    rs = np.random.RandomState(5)
+    B, T = 3, 8
+    seq_len = np.array([8, 6, 8])
+    feats = rs.randn(B, T, 6)
+    labels = rs.randint(0, 4, size=(B, 3))
+    label_len = np.array([3, 2, 1])
+    params = [p + 0.3 * rs.randn(*p.shape) for p in O.init_params(spec, seed=3)]
+    drop = (1234, 7)
+    masks = [O.dropout_mask(1234, 7, i, T, B, w, spec.drop_p(i)) for i, w in enumerate(list(spec.pre) + [spec.post])]
+    assert 0.5 < masks[0].mean() < 0.9 and not masks[0].all()
+    loss, nll, grads, logits = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len, drop=drop)
+    tp = [torch.tensor(p, requires_grad=True) for p in params]
+    tlogits, tloss = _torch_deepspeech(spec, tp, feats, seq_len, labels, label_len, masks)
+    tloss.backward()
+    np.testing.assert_allclose(logits, tlogits.detach().numpy(), atol=1e-12)
+    assert loss == pytest.approx(float(tloss.detach()), rel=1e-12)
+    for n, g, t in zip(names, grads, tp):
+        np.testing.assert_allclose(g, t.grad.numpy(), atol=1e-11, err_msg=n)
+    # without dropout the masks are all ones
+    l0 = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)[0]
+    assert l0 != loss
+
+
+def test_dropout_mask_is_a_pure_function_of_its_key():
+    a = O.dropout_mask(1, 2, 0, 4, 3, 5, 0.5)
+    assert (a == O.dropout_mask(1, 2, 0, 4, 3, 5, 0.5)).all()
+    assert (a != O.dropout_mask(1, 3, 0, 4, 3, 5, 0.5)).any() and (a != O.dropout_mask(1, 2, 1, 4, 3, 5, 0.5)).any()
+    big = O.dropout_mask(9, 9, 2, 50, 8, 64, 0.05)
+    assert abs(big.mean() - 0.95) < 0.01
