@@ -54,6 +54,15 @@ typedef struct {
   float forget_bias;     /* 1.0 (BasicLSTMCell / LSTMCell default) */
   float learning_rate;   /* config.learningrate */
   float beta1, beta2, epsilon; /* 0.9, 0.999, 1e-8 */
+  /* DeepSpeech family (networks/deepspeech.py:10-132): clipped-ReLU dense stages with dropout in front of the LSTM
+   * stack (layers 1-3: widths n_hidden, n_hidden, 2*n_cell_dim) and one between the stack and the logits (layer 5).
+   * All zero for the (Bi)LstmCTCNet models.  With any of them set the variable order is the creation order of
+   * deepspeech.py: b1,h1,b2,h2,b3,h3, fw kernel, fw bias, bw kernel, bw bias, b5,h5, b6,h6 (bias BEFORE weight). */
+  int32_t num_pre;       /* 0..3 dense stages before the stack */
+  int32_t pre_width[3];
+  int32_t post_width;    /* 0 = none */
+  float relu_clip;       /* 20.0 */
+  float dropout[4];      /* drop probability of the pre stages, then of the post stage ([0.05,0.05,0.05] and 0.05) */
 } nasr_model_cfg;
 
 /* Phase timings of the last nasr_compute_grads / nasr_apply_adam (HIP events on the handle's
@@ -163,6 +172,13 @@ int nasr_ctc_beam_search(const float* logits, const int32_t* seq_len, int B, int
  * labels [B,Lmax].  An empty truth gives inf for a non-empty hypothesis and 0 otherwise, as TF does. */
 int nasr_label_error_rate(const int32_t* hyp_ids, const int32_t* hyp_lens, int hyp_stride, const int32_t* labels,
                           const int32_t* label_len, int Lmax, int B, float* ler_out);
+
+/* tf.nn.dropout of the dense stages (networks/deepspeech.py:50,59,68,113; applied in every graph, training or not).
+ * TensorFlow's random stream is not reproducible, so the keep-mask of forward pass number `counter` is a pure function
+ * of (seed, counter, stage, frame, utterance, unit): see neuralasr_amd/csrc/dense.hip.  Every forward pass uses the
+ * current counter and then increments it; nasr_set_dropout_state pins both (tests, resuming). */
+int nasr_set_dropout_state(nasr_handle h, uint32_t seed, uint32_t counter);
+int nasr_get_dropout_state(nasr_handle h, uint32_t* seed, uint32_t* counter);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 int nasr_set_profiling(nasr_handle h, int enabled); /* record HIP events around the phases */

@@ -2,7 +2,7 @@
 missing or no gfx950 device is usable, everything here raises."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, byref, c_char, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, byref, c_char, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libnasr.so')
@@ -25,14 +25,16 @@ SYMBOLS = [
     'nasr_grad_device_ptr', 'nasr_grad_device_count', 'nasr_apply_adam', 'nasr_get_grads', 'nasr_set_grads',
     'nasr_upload_batch_context', 'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_ctc_beam_search', 'nasr_get_loss', 'nasr_resident_frames',
     'nasr_set_profiling', 'nasr_get_phase_times', 'nasr_set_graph_mode',
-    'nasr_get_recurrence_mode', 'nasr_set_recurrence_mode',
+    'nasr_get_recurrence_mode', 'nasr_set_recurrence_mode', 'nasr_set_dropout_state', 'nasr_get_dropout_state',
 ]
 
 
 class ModelCfg(Structure):
     _fields_ = [('feature_size', c_int32), ('hidden', c_int32), ('num_layers', c_int32), ('bidirectional', c_int32),
                 ('merge', c_int32), ('num_classes', c_int32), ('forget_bias', c_float), ('learning_rate', c_float),
-                ('beta1', c_float), ('beta2', c_float), ('epsilon', c_float)]
+                ('beta1', c_float), ('beta2', c_float), ('epsilon', c_float),
+                ('num_pre', c_int32), ('pre_width', c_int32 * 3), ('post_width', c_int32), ('relu_clip', c_float),
+                ('dropout', c_float * 4)]
 
 
 class PhaseTimes(Structure):
@@ -107,6 +109,8 @@ def load():
         'nasr_set_graph_mode': (c_int, [H, c_int]),
         'nasr_get_recurrence_mode': (c_int, [H]),
         'nasr_set_recurrence_mode': (c_int, [H, c_int]),
+        'nasr_set_dropout_state': (c_int, [H, c_uint32, c_uint32]),
+        'nasr_get_dropout_state': (c_int, [H, POINTER(c_uint32), POINTER(c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

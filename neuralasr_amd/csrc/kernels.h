@@ -105,6 +105,11 @@ void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* 
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
                              hipStream_t st);
 
+// ---- DeepSpeech dense stages (dense.hip): clipped ReLU + hash-defined dropout, in place ----
+void launch_dense_act(float* z, int R, int Bp, int B, int W, int ld, float clip, float p, uint32_t seed, uint32_t counter,
+                      int stage, hipStream_t st);
+void launch_dense_act_bwd(float* dy, const float* y, int64_t n, float clip, float p, hipStream_t st);
+
 // ---- CTC (ctc.hip) ----
 struct CtcDims {
   int Tp;      // logit frames T'

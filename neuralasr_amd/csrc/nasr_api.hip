@@ -111,6 +111,19 @@ struct nasr_ctx {
   int64_t np_tf = 0;
   std::vector<int32_t> tf2int;          // TF flat index -> internal flat index
 
+  // dense stages of the DeepSpeech family (networks/deepspeech.py): stage i < npre feeds the LSTM stack, stage npre
+  // (when has_post) sits between the stack and the logits.  W_i [dIp][dWp] row-major, b_i [dWp].
+  int npre = 0, ndense = 0;
+  bool has_post = false;
+  int F0 = 0;                            // unpadded input width of LSTM layer 0 (F, or the last pre stage's width)
+  std::vector<int> dWid, dWp, dIn, dIp;
+  std::vector<int64_t> off_dw, off_db;
+  std::vector<size_t> off_dftp, off_dbtp;
+  unsigned char *DfTP = nullptr, *DbTP = nullptr;   // TP of W_i^T [dWp][dIp] and of W_i [dIp][dWp]
+  std::vector<DevBuf> Ybuf, dYbuf;       // stage outputs and their gradients [R][dWp]
+  DevBuf DTP;                            // scratch: TP of a stage input with the frame index as contraction index
+  uint32_t drop_seed = 4567u, drop_counter = 0;   // random_seed of networks/deepspeech.py:26
+
   float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *Uf = nullptr, *Ub = nullptr;
   float* WxT = nullptr;                // per layer [D*N4][Ip]: transposed input weights (K-contiguous B operand)
   std::vector<int64_t> off_wxt;
@@ -226,17 +239,40 @@ int build_layout(nasr_ctx* h) {
   h->N4 = 4 * h->Hp;
   h->Cp = rup(h->C, 32);
   const bool concat = c.bidirectional && c.merge == NASR_MERGE_CONCAT;
-  h->Pin = concat ? 2 * h->H : h->H;
-  h->Pinp = concat ? 2 * h->Hp : h->Hp;
   const int D = h->D, Hp = h->Hp, N4 = h->N4, H = h->H;
+  const int lstm_out = concat ? 2 * H : H, lstm_outp = concat ? 2 * Hp : Hp;
+
+  // dense stages
+  h->npre = c.num_pre;
+  h->has_post = c.post_width > 0;
+  h->ndense = h->npre + (h->has_post ? 1 : 0);
+  h->dWid.assign(h->ndense, 0); h->dWp.assign(h->ndense, 0); h->dIn.assign(h->ndense, 0); h->dIp.assign(h->ndense, 0);
+  for (int i = 0; i < h->npre; ++i) {
+    h->dWid[i] = c.pre_width[i]; h->dWp[i] = rup(c.pre_width[i], 64);
+    h->dIn[i] = i == 0 ? h->F : h->dWid[i - 1];
+    h->dIp[i] = i == 0 ? h->Fp : h->dWp[i - 1];
+  }
+  if (h->has_post) {
+    const int i = h->npre;
+    h->dWid[i] = c.post_width; h->dWp[i] = rup(c.post_width, 64);
+    h->dIn[i] = lstm_out; h->dIp[i] = lstm_outp;
+  }
+  h->F0 = h->npre ? h->dWid[h->npre - 1] : h->F;
+  h->Pin = h->has_post ? c.post_width : lstm_out;
+  h->Pinp = h->has_post ? h->dWp[h->npre] : lstm_outp;
 
   int64_t off = 0;
+  h->off_dw.assign(h->ndense, 0); h->off_db.assign(h->ndense, 0);
+  for (int i = 0; i < h->ndense; ++i) {
+    h->off_dw[i] = off; off += (int64_t)h->dIp[i] * h->dWp[i];
+    h->off_db[i] = off; off += h->dWp[i];
+  }
   h->Ip.resize(h->L);
   h->off_wx.resize(h->L);
   h->off_bias.resize(h->L);
   h->off_u.resize((size_t)h->L * D);
   for (int l = 0; l < h->L; ++l) {
-    h->Ip[l] = l == 0 ? h->Fp : D * Hp;
+    h->Ip[l] = l == 0 ? (h->npre ? h->dWp[h->npre - 1] : h->Fp) : D * Hp;
     h->off_wx[l] = off;
     off += (int64_t)h->Ip[l] * D * N4;
     h->off_bias[l] = off;
@@ -253,15 +289,21 @@ int build_layout(nasr_ctx* h) {
   h->np_int = off;  // every term is a multiple of 32
   if (off >= (int64_t)1 << 31) return h->fail(NASR_ERR_ARG, "model too large for 32-bit parameter indexing");
 
-  // TF variable order + element map
+  // TF variable order + element map.  Plain (Bi)LstmCTCNet: cells, W, b.  DeepSpeech family (creation order of
+  // networks/deepspeech.py): b1,h1,b2,h2,b3,h3, cells, b5,h5, b6,h6.
+  const bool ds = h->ndense > 0;
   h->tensors.clear();
   int64_t tfo = 0;
   auto add = [&](const std::string& n, int64_t r, int64_t cc) {
     h->tensors.push_back({n, tfo, r, cc});
     tfo += r * cc;
   };
+  for (int i = 0; i < h->npre; ++i) {
+    add("b" + std::to_string(i + 1), h->dWid[i], 1);
+    add("h" + std::to_string(i + 1), h->dIn[i], h->dWid[i]);
+  }
   for (int l = 0; l < h->L; ++l) {
-    const int I = l == 0 ? h->F : D * H;
+    const int I = l == 0 ? h->F0 : D * H;
     for (int d = 0; d < D; ++d) {
       std::string pre = "l" + std::to_string(l) + "/";
       if (D == 2) pre += d == 0 ? "fw/" : "bw/";
@@ -269,13 +311,35 @@ int build_layout(nasr_ctx* h) {
       add(pre + "bias", 4 * H, 1);
     }
   }
-  add("W", h->Pin, h->C);
-  add("b", h->C, 1);
+  if (ds) {
+    if (h->has_post) {
+      add("b5", h->dWid[h->npre], 1);
+      add("h5", h->dIn[h->npre], h->dWid[h->npre]);
+    }
+    add("b6", h->C, 1);
+    add("h6", h->Pin, h->C);
+  } else {
+    add("W", h->Pin, h->C);
+    add("b", h->C, 1);
+  }
   h->np_tf = tfo;
   h->tf2int.assign((size_t)tfo, 0);
   size_t ti = 0;
+  // rows of a matrix fed by the concatenated (fw, bw) outputs: the bw half starts at the padded width
+  auto cat_row = [&](int r) { return (D == 2 && concat && r >= H) ? Hp + (r - H) : r; };
+  auto map_dense = [&](int i, bool from_lstm) {
+    const TensorInfo& tb = h->tensors[ti++];
+    for (int cc = 0; cc < h->dWid[i]; ++cc) h->tf2int[(size_t)(tb.offset + cc)] = (int32_t)(h->off_db[i] + cc);
+    const TensorInfo& tw = h->tensors[ti++];
+    for (int r = 0; r < h->dIn[i]; ++r) {
+      const int ir = from_lstm ? cat_row(r) : r;
+      for (int cc = 0; cc < h->dWid[i]; ++cc)
+        h->tf2int[(size_t)(tw.offset + (int64_t)r * h->dWid[i] + cc)] = (int32_t)(h->off_dw[i] + (int64_t)ir * h->dWp[i] + cc);
+    }
+  };
+  for (int i = 0; i < h->npre; ++i) map_dense(i, false);
   for (int l = 0; l < h->L; ++l) {
-    const int I = l == 0 ? h->F : D * H;
+    const int I = l == 0 ? h->F0 : D * H;
     for (int d = 0; d < D; ++d) {
       const TensorInfo& tk = h->tensors[ti++];
       for (int r = 0; r < I + H; ++r) {
@@ -299,17 +363,20 @@ int build_layout(nasr_ctx* h) {
       }
     }
   }
-  {
+  if (h->has_post) map_dense(h->npre, true);
+  auto map_w = [&]() {
     const TensorInfo& tw = h->tensors[ti++];
     for (int r = 0; r < h->Pin; ++r) {
-      int ir = r;
-      if (concat && r >= H) ir = Hp + (r - H);
+      const int ir = h->has_post ? r : cat_row(r);
       for (int cc = 0; cc < h->C; ++cc)
         h->tf2int[(size_t)(tw.offset + (int64_t)r * h->C + cc)] = (int32_t)(h->off_w + (int64_t)ir * h->Cp + cc);
     }
+  };
+  auto map_b = [&]() {
     const TensorInfo& tb = h->tensors[ti++];
     for (int cc = 0; cc < h->C; ++cc) h->tf2int[(size_t)(tb.offset + cc)] = (int32_t)(h->off_b + cc);
-  }
+  };
+  if (ds) { map_b(); map_w(); } else { map_w(); map_b(); }
   return NASR_OK;
 }
 
@@ -324,8 +391,13 @@ int repack(nasr_ctx* h) {
   if (h->gemm_tp) {
     for (int l = 0; l < h->L; ++l) {
       launch_tp_split(h->P + h->off_wx[l], h->WfTP + h->off_wftp[l], h->D * h->N4, h->Ip[l], h->D * h->N4, true, h->st);
-      if (l > 0)
+      if (l > 0 || h->npre > 0)
         launch_tp_split(h->P + h->off_wx[l], h->WbTP + h->off_wbtp[l], h->Ip[l], h->D * h->N4, h->D * h->N4, false, h->st);
+    }
+    for (int i = 0; i < h->ndense; ++i) {
+      launch_tp_split(h->P + h->off_dw[i], h->DfTP + h->off_dftp[i], h->dWp[i], h->dIp[i], h->dWp[i], true, h->st);
+      if (i > 0 || h->npre == 0)   // the first pre stage reads the features: no gradient wrt its input
+        launch_tp_split(h->P + h->off_dw[i], h->DbTP + h->off_dbtp[i], h->dIp[i], h->dWp[i], h->dWp[i], false, h->st);
     }
   } else if (h->gemm_bf16)
     for (int l = 0; l < h->L; ++l)
@@ -371,14 +443,16 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
     ok &= h->dgL[i].ensure(R * D * N4 * 4, &grew);
   }
   if (h->gemm_tp) {
-    int ipmax = h->Fp;
+    int ipmax = h->Fp, wmax = D * N4;
     for (int l = 0; l < h->L; ++l) ipmax = std::max(ipmax, h->Ip[l]);
+    for (int i = 0; i < h->ndense; ++i) { ipmax = std::max(ipmax, h->dIp[i]); wmax = std::max(wmax, h->dWp[i]); }
     ok &= h->XTP.ensure(tp_bytes((int)R, ipmax), &grew);
-    ok &= h->X0TTP.ensure(tp_bytes(h->Fp, (int)R), &grew);
+    ok &= h->X0TTP.ensure(tp_bytes(h->Ip[0], (int)R), &grew);
     ok &= h->OTTP0.ensure(tp_bytes(D * Hp, (int)R), &grew);
     ok &= h->OTTP1.ensure(tp_bytes(D * Hp, (int)R), &grew);
-    ok &= h->GTP.ensure(tp_bytes((int)R, D * N4), &grew);
-    ok &= h->GTTP.ensure(tp_bytes(D * N4, (int)R), &grew);
+    ok &= h->GTP.ensure(tp_bytes((int)R, wmax), &grew);
+    ok &= h->GTTP.ensure(tp_bytes(wmax, (int)R), &grew);
+    if (h->ndense) ok &= h->DTP.ensure(tp_bytes(ipmax, (int)R), &grew);
   } else if (h->gemm_bf16) {
     ok &= h->X0T.ensure(R * h->Fp * 4, &grew);
     ok &= h->outT0.ensure(R * D * Hp * 4, &grew);
@@ -399,10 +473,16 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->labels.ensure((size_t)std::max(1, B * std::max(Lmax, 1)) * 4, &grew);
   ok &= h->lablen.ensure((size_t)Bp * 4, &grew);
   ok &= h->rowmap.ensure((size_t)Tp * Bp * 4, &grew);
-  ok &= h->csws.ensure((size_t)32 * std::max(D * N4, h->Cp) * 4, &grew);
+  int csw = std::max(D * N4, h->Cp);
+  for (int i = 0; i < h->ndense; ++i) csw = std::max(csw, h->dWp[i]);
+  ok &= h->csws.ensure((size_t)32 * csw * 4, &grew);
   ok &= h->amax.ensure((size_t)Tp * Bp * 4, &grew);
   ok &= h->ids.ensure((size_t)B * Tp * 4, &grew);
   ok &= h->lens.ensure((size_t)Bp * 4, &grew);
+  for (int i = 0; i < h->ndense; ++i) {
+    ok &= h->Ybuf[i].ensure(R * h->dWp[i] * 4, &grew);
+    ok &= h->dYbuf[i].ensure(R * h->dWp[i] * 4, &grew);
+  }
   for (int l = 0; l < h->L; ++l) {
     ok &= h->gates[l].ensure(R * D * N4 * 4, &grew);
     ok &= h->outb[l].ensure(R * D * Hp * 4, &grew);
@@ -506,7 +586,7 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
     else
       launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
     if (h->gemm_tp) {
-      if (labels)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
+      if (labels && h->npre == 0)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
         launch_tp_split(h->X0.as<float>(), h->X0TTP.as<unsigned char>(), h->Fp, T * Bp, h->Fp, true, h->st);
     } else if (h->gemm_bf16 && labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
       launch_transpose(h->X0.as<float>(), h->X0T.as<float>(), T * Bp, h->Fp, h->Fp, T * Bp, h->st);
@@ -595,10 +675,16 @@ float* ensure_slabs(nasr_ctx* h, int split, int M, int N) {
   return h->slabs.as<float>();
 }
 
+// input of LSTM layer l: the features, the last pre-dense stage's output, or the layer below
+inline const float* lstm_input(nasr_ctx* h, int l) {
+  if (l > 0) return h->outb[l - 1].as<float>();
+  return h->npre ? h->Ybuf[h->npre - 1].as<float>() : h->X0.as<float>();
+}
+
 // gates_l[r0 .. r0+nr) = X_l[r0 ..] * Wx_l + bias_l   (rows are time-major, so a time chunk is a row range)
 void gemm_xproj(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
   const int D = h->D, N4 = h->N4, Ip = h->Ip[l];
-  const float* Xl = (l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>()) + (size_t)r0 * Ip;
+  const float* Xl = lstm_input(h, l) + (size_t)r0 * Ip;
   float* C = h->gates[l].as<float>() + (size_t)r0 * D * N4;
   if (h->gemm_tp) {
     launch_tp_split(Xl, h->XTP.as<unsigned char>(), nr, Ip, Ip, false, st);
@@ -626,13 +712,13 @@ void gemm_xproj(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
 void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
   const int D = h->D, N4 = h->N4, Hp = h->Hp;
   const float* A = dg_of(h, l) + (size_t)r0 * D * N4;
-  float* C = dout_of(h, l - 1) + (size_t)r0 * D * Hp;
+  float* C = l > 0 ? dout_of(h, l - 1) + (size_t)r0 * D * Hp : h->dYbuf[h->npre - 1].as<float>() + (size_t)r0 * h->Ip[0];
   if (h->gemm_tp) {
     launch_tp_split(A, h->GTP.as<unsigned char>(), nr, D * N4, D * N4, false, st);
     GemmTPDesc g{};
     g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
-    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * Hp;
-    g.split_k = g.ldc == g.N ? gemm_tp_pick_split(g.M, g.N, g.K) : 1;
+    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = h->Ip[l];
+    g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) g.split_k = 1;
     launch_gemm_tp(g, st);
@@ -650,6 +736,54 @@ void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
   }
 }
 
+// ---- dense stages (networks/deepspeech.py:43-68,106-113) -----------------------------------------------------
+// Y_i = dropout(min(relu(X W_i + b_i), clip)): one tiled-plane GEMM + the in-place epilogue of dense.hip
+int dense_forward(nasr_ctx* h, int i, const float* X) {
+  const int R = h->T * h->Bp, Ip = h->dIp[i], Wp = h->dWp[i];
+  launch_tp_split(X, h->XTP.as<unsigned char>(), R, Ip, Ip, false, h->st);
+  GemmTPDesc g{};
+  g.A = h->XTP.as<unsigned char>(); g.B = h->DfTP + h->off_dftp[i]; g.C = h->Ybuf[i].as<float>();
+  g.M = R; g.N = Wp; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = Wp;
+  g.bias = h->P + h->off_db[i]; g.split_k = 1;
+  launch_gemm_tp(g, h->st);
+  launch_dense_act(h->Ybuf[i].as<float>(), R, h->Bp, h->B, h->dWid[i], Wp, h->cfg.relu_clip, h->cfg.dropout[i],
+                   h->drop_seed, h->drop_counter, i, h->st);
+  HIPCHK(h, hipGetLastError());
+  return NASR_OK;
+}
+
+// dY_i (in dYbuf[i]) -> dW_i, db_i and, when dX is given, the gradient wrt the stage's input [R][dIp]
+int dense_backward(nasr_ctx* h, int i, const float* X, float* dX) {
+  const int R = h->T * h->Bp, Ip = h->dIp[i], Wp = h->dWp[i];
+  const int nkb = (R + 15) / 16;
+  float* dZ = h->dYbuf[i].as<float>();
+  launch_dense_act_bwd(dZ, h->Ybuf[i].as<float>(), (int64_t)R * Wp, h->cfg.relu_clip, h->cfg.dropout[i], h->st);
+  launch_tp_split(dZ, h->GTTP.as<unsigned char>(), Wp, R, Wp, true, h->st);
+  launch_tp_split(X, h->DTP.as<unsigned char>(), Ip, R, Ip, true, h->st);
+  {  // dW = X^T dZ
+    GemmTPDesc g{};
+    g.A = h->DTP.as<unsigned char>(); g.B = h->GTTP.as<unsigned char>(); g.C = h->G + h->off_dw[i];
+    g.M = Ip; g.N = Wp; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = Wp;
+    g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+    if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+    launch_gemm_tp(g, h->st);
+  }
+  launch_colsum(dZ, R, Wp, Wp, h->G + h->off_db[i], h->csws.as<float>(), h->st);
+  if (dX) {  // dX = dZ W^T
+    launch_tp_split(dZ, h->GTP.as<unsigned char>(), R, Wp, Wp, false, h->st);
+    GemmTPDesc g{};
+    g.A = h->GTP.as<unsigned char>(); g.B = h->DbTP + h->off_dbtp[i]; g.C = dX;
+    g.M = R; g.N = Ip; g.K = Wp; g.nkbA = (Wp + 15) / 16; g.nkbB = g.nkbA; g.ldc = Ip;
+    g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+    if (g.split_k > 1 && !g.slabs) g.split_k = 1;
+    launch_gemm_tp(g, h->st);
+  }
+  HIPCHK(h, hipGetLastError());
+  return NASR_OK;
+}
+
 int pipe_fork(nasr_ctx* h) {
   HIPCHK(h, hipEventRecord(h->ev_fork, h->st));
   for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->lst[l], h->ev_fork, 0));
@@ -662,6 +796,11 @@ int forward(nasr_ctx* h) {
   const int R = T * Bp;
   h->n_fwd_launch = 0;
   const int NC = h->pipe_chunks;
+  for (int i = 0; i < h->npre; ++i) {
+    PhaseScope ps(h, PH_XPROJ);
+    int rc = dense_forward(h, i, i == 0 ? h->X0.as<float>() : h->Ybuf[i - 1].as<float>());
+    if (rc) return rc;
+  }
   if (NC <= 1) {
     for (int l = 0; l < h->L; ++l) {
       {
@@ -697,15 +836,21 @@ int forward(nasr_ctx* h) {
     h->n_fwd_launch = T + (h->L - 1) * Tc;   // length of the critical path in step launches
     HIPCHK(h, hipGetLastError());
   }
+  if (h->has_post) {
+    PhaseScope ps(h, PH_XPROJ);
+    int rc = dense_forward(h, h->npre, h->outb[h->L - 1].as<float>());
+    if (rc) return rc;
+  }
+  if (h->ndense) h->drop_counter += 1;   // one counter value per forward pass
   {
     PhaseScope ps(h, PH_PROJCTC);
     const bool sr = h->cfg.merge == NASR_MERGE_STACK_RESHAPE && D == 2;
     GemmDesc g{};
-    g.A = h->outb[h->L - 1].as<float>();
+    g.A = h->has_post ? h->Ybuf[h->npre].as<float>() : h->outb[h->L - 1].as<float>();
     g.B = h->P + h->off_w;
     g.C = h->logits.as<float>();
     g.M = h->Tp * Bp; g.N = h->Cp; g.K = h->Pinp;
-    g.lda = sr ? Hp : D * Hp; g.ldb = h->Cp; g.ldc = h->Cp;
+    g.lda = sr ? Hp : h->Pinp; g.ldb = h->Cp; g.ldc = h->Cp;
     g.a_map = sr ? h->rowmap.as<int>() : nullptr;
     g.a_rows = sr ? 2 * R : R;
     g.bias = h->P + h->off_b; g.split_k = 1;
@@ -746,7 +891,7 @@ int weight_grads(nasr_ctx* h, int l) {
   const int R = T * Bp;
   float* dG = dg_of(h, l);
   hipStream_t ws = h->st;
-  const float* Xl = l == 0 ? h->X0.as<float>() : h->outb[l - 1].as<float>();
+  const float* Xl = lstm_input(h, l);
   if (h->gemm_tp) {
     // tiled-plane copies with the frame index as contraction index (K = R)
     unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
@@ -755,6 +900,7 @@ int weight_grads(nasr_ctx* h, int l) {
     launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);
     if (l == h->L - 1) launch_tp_split(h->outb[l].as<float>(), tO[l & 1], D * Hp, R, D * Hp, true, ws);
     if (l > 0) launch_tp_split(h->outb[l - 1].as<float>(), tO[(l - 1) & 1], D * Hp, R, D * Hp, true, ws);
+    if (l == 0 && h->npre) launch_tp_split(Xl, h->X0TTP.as<unsigned char>(), h->Ip[0], R, h->Ip[0], true, ws);
     {  // dWx = X^T dG
       GemmTPDesc g{};
       g.A = l == 0 ? h->X0TTP.as<unsigned char>() : tO[(l - 1) & 1];
@@ -856,11 +1002,11 @@ int backward(nasr_ctx* h) {
     PhaseScope ps(h, PH_PROJB);
     // dW = gather(out)^T dlogits
     GemmDesc g{};
-    g.A = h->outb[h->L - 1].as<float>();
+    g.A = h->has_post ? h->Ybuf[h->npre].as<float>() : h->outb[h->L - 1].as<float>();
     g.B = h->logits.as<float>();
     g.C = h->G + h->off_w;
     g.M = h->Pinp; g.N = h->Cp; g.K = Rp;
-    g.lda = sr ? Hp : D * Hp; g.ldb = h->Cp; g.ldc = h->Cp;
+    g.lda = sr ? Hp : h->Pinp; g.ldb = h->Cp; g.ldc = h->Cp;
     g.a_col = true; g.a_map = sr ? h->rowmap.as<int>() : nullptr; g.a_rows = sr ? 2 * R : R;
     g.split_k = gemm_pick_split(g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
@@ -871,12 +1017,17 @@ int backward(nasr_ctx* h) {
     GemmDesc x{};
     x.A = h->logits.as<float>();
     x.B = h->P + h->off_w;
-    x.C = dout_of(h, h->L - 1);
+    x.C = h->has_post ? h->dYbuf[h->npre].as<float>() : dout_of(h, h->L - 1);
     x.M = Rp; x.N = h->Pinp; x.K = h->Cp;
-    x.lda = h->Cp; x.ldb = h->Cp; x.ldc = sr ? Hp : D * Hp;
+    x.lda = h->Cp; x.ldb = h->Cp; x.ldc = sr ? Hp : h->Pinp;
     x.b_col = true; x.a_rows = Rp; x.c_map = sr ? h->rowmap.as<int>() : nullptr; x.split_k = 1;
     launch_gemm(x, h->st);
     HIPCHK(h, hipGetLastError());
+  }
+  if (h->has_post) {
+    PhaseScope ps(h, PH_WGRAD);
+    int rc = dense_backward(h, h->npre, h->outb[h->L - 1].as<float>(), dout_of(h, h->L - 1));
+    if (rc) return rc;
   }
   h->n_bwd_launch = 0;
   const int NC = h->pipe_chunks;
@@ -889,7 +1040,7 @@ int backward(nasr_ctx* h) {
         h->n_bwd_launch += h->persist ? 1 : T;
       }
       PhaseScope ps(h, PH_WGRAD);
-      if (l > 0) gemm_dx(h, l, 0, R, h->st);   // critical path first
+      if (l > 0 || h->npre > 0) gemm_dx(h, l, 0, R, h->st);   // critical path first
       int rc = weight_grads(h, l);
       if (rc) return rc;
     }
@@ -921,6 +1072,12 @@ int backward(nasr_ctx* h) {
       int rc = weight_grads(h, l);
       if (rc) return rc;
     }
+  }
+  for (int i = h->npre - 1; i >= 0; --i) {
+    PhaseScope ps(h, PH_WGRAD);
+    int rc = dense_backward(h, i, i == 0 ? h->X0.as<float>() : h->Ybuf[i - 1].as<float>(),
+                            i > 0 ? h->dYbuf[i - 1].as<float>() : nullptr);
+    if (rc) return rc;
   }
   h->have_grads = true;
   return NASR_OK;
@@ -955,6 +1112,28 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   }
   if (cfg->bidirectional && cfg->merge != NASR_MERGE_STACK_RESHAPE && cfg->merge != NASR_MERGE_CONCAT) {
     g_create_error = "nasr_create: bidirectional nets need merge = STACK_RESHAPE or CONCAT";
+    return NASR_ERR_ARG;
+  }
+  if (cfg->num_pre < 0 || cfg->num_pre > 3 || cfg->post_width < 0) {
+    g_create_error = "nasr_create: num_pre must be in [0,3] and post_width >= 0";
+    return NASR_ERR_ARG;
+  }
+  for (int i = 0; i < cfg->num_pre; ++i)
+    if (cfg->pre_width[i] < 1) {
+      g_create_error = "nasr_create: pre_width[i] must be >= 1 for i < num_pre";
+      return NASR_ERR_ARG;
+    }
+  for (int i = 0; i < 4; ++i)
+    if (!(cfg->dropout[i] >= 0.f && cfg->dropout[i] < 1.f)) {
+      g_create_error = "nasr_create: dropout probabilities must be in [0,1)";
+      return NASR_ERR_ARG;
+    }
+  if ((cfg->num_pre > 0 || cfg->post_width > 0) && !(cfg->relu_clip > 0.f)) {
+    g_create_error = "nasr_create: relu_clip must be > 0 when dense stages are present";
+    return NASR_ERR_ARG;
+  }
+  if ((cfg->num_pre > 0 || cfg->post_width > 0) && cfg->bidirectional && cfg->merge != NASR_MERGE_CONCAT) {
+    g_create_error = "nasr_create: the DeepSpeech family concatenates the directions (merge = CONCAT)";
     return NASR_ERR_ARG;
   }
   if (cfg->bidirectional && cfg->merge == NASR_MERGE_STACK_RESHAPE && cfg->num_layers != 1) {
@@ -1005,18 +1184,28 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     const char* ep = getenv("NASR_PIPE");
     const char* es = getenv("NASR_PERSIST");
     const bool persist_cand = !(es && es[0] == '0') && persist_supported(h->Hp) && prop.multiProcessorCount == 256;
-    const bool pipe_cand = h->D == 1 && h->L > 1 && !(ep && ep[0] == '0') && !persist_cand;
+    const bool pipe_cand = h->D == 1 && h->L > 1 && !(ep && ep[0] == '0') && !persist_cand && h->ndense == 0;
     h->gemm_tp = h->gemm_bf16 && !(e && std::string(e) == "bf16") && !pipe_cand;
     if (h->gemm_tp) {
       size_t of = 0, ob = 0;
       h->off_wftp.resize(h->L); h->off_wbtp.resize(h->L);
       for (int l = 0; l < h->L; ++l) {
         h->off_wftp[l] = of; of += tp_bytes(h->D * h->N4, h->Ip[l]);
-        h->off_wbtp[l] = ob; if (l > 0) ob += tp_bytes(h->Ip[l], h->D * h->N4);
+        h->off_wbtp[l] = ob; if (l > 0 || h->npre > 0) ob += tp_bytes(h->Ip[l], h->D * h->N4);
+      }
+      size_t df = 0, db = 0;
+      h->off_dftp.assign(h->ndense, 0); h->off_dbtp.assign(h->ndense, 0);
+      for (int i = 0; i < h->ndense; ++i) {
+        h->off_dftp[i] = df; df += tp_bytes(h->dWp[i], h->dIp[i]);
+        h->off_dbtp[i] = db; if (i > 0 || h->npre == 0) db += tp_bytes(h->dIp[i], h->dWp[i]);
       }
       if (gemm_tp_prepare() != hipSuccess || hipMalloc(&h->WfTP, of) != hipSuccess ||
-          hipMalloc(&h->WbTP, std::max<size_t>(ob, 1024)) != hipSuccess)
+          hipMalloc(&h->WbTP, std::max<size_t>(ob, 1024)) != hipSuccess ||
+          hipMalloc(&h->DfTP, std::max<size_t>(df, 1024)) != hipSuccess ||
+          hipMalloc(&h->DbTP, std::max<size_t>(db, 1024)) != hipSuccess)
         return bail(NASR_ERR_HIP, "hipMalloc of the tiled weight planes failed");
+    } else if (h->ndense) {
+      return bail(NASR_ERR_ARG, "the dense stages of the DeepSpeech family need the tiled-plane GEMMs (NASR_GEMM unset or tp)");
     }
     int64_t o = 0;
     h->off_wxt.resize(h->L);
@@ -1060,13 +1249,15 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   h->gates.resize(h->L);
   h->outb.resize(h->L);
   h->cbuf.resize(h->L);
+  h->Ybuf.resize(h->ndense);
+  h->dYbuf.resize(h->ndense);
   {
     // Tried and removed (measured on MI355X, 3x500 bi, B 16, T 500): running the weight-gradient GEMMs of layer l on
     // a low-priority side stream under the BPTT of layer l-1 slowed the latency-bound BPTT launches by 30 % and the
     // step got 0.5 ms LONGER.  What does pay is pipelining the layers of a UNIdirectional stack, whose step launches
     // fill only half the CUs: per-layer streams, time chunks, events (NASR_PIPE=0 disables).
     const char* e = getenv("NASR_PIPE");
-    h->pipe = h->D == 1 && h->L > 1 && !(e && e[0] == '0') && !h->persist;
+    h->pipe = h->D == 1 && h->L > 1 && !(e && e[0] == '0') && !h->persist && h->ndense == 0;
     const size_t nl = h->pipe ? (size_t)h->L : 1;
     h->doutL.resize(nl); h->hstateL.resize(nl); h->partialL.resize(nl); h->dcstateL.resize(nl); h->dgL.resize(nl);
     h->lst.assign((size_t)h->L, h->st);
@@ -1134,6 +1325,11 @@ int nasr_destroy(nasr_handle h) {
     if (p) (void)hipFree(p);
   if (h->WfTP) (void)hipFree(h->WfTP);
   if (h->WbTP) (void)hipFree(h->WbTP);
+  if (h->DfTP) (void)hipFree(h->DfTP);
+  if (h->DbTP) (void)hipFree(h->DbTP);
+  h->DTP.release();
+  for (auto& b : h->Ybuf) b.release();
+  for (auto& b : h->dYbuf) b.release();
   if (h->pctl) (void)hipFree(h->pctl);
   if (h->perr) (void)hipHostFree(h->perr);
   for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->OTTP0, &h->OTTP1, &h->GTP, &h->GTTP}) b->release();
@@ -1474,6 +1670,20 @@ int nasr_set_graph_mode(nasr_handle h, int enabled) {
   if (!h) return NASR_ERR_ARG;
   h->graph_mode = enabled != 0;
   if (!h->graph_mode) drop_graphs(h);
+  return NASR_OK;
+}
+
+int nasr_set_dropout_state(nasr_handle h, uint32_t seed, uint32_t counter) {
+  if (!h) return NASR_ERR_ARG;
+  h->drop_seed = seed;
+  h->drop_counter = counter;
+  return NASR_OK;
+}
+
+int nasr_get_dropout_state(nasr_handle h, uint32_t* seed, uint32_t* counter) {
+  if (!h) return NASR_ERR_ARG;
+  if (seed) *seed = h->drop_seed;
+  if (counter) *counter = h->drop_counter;
   return NASR_OK;
 }
 

@@ -2,7 +2,7 @@
 `Network` plugin classes (neuralasr_amd/networks) and bench.py sit on; all arithmetic happens in the HIP
 library behind include/nasr.h."""
 import ctypes
-from ctypes import POINTER, byref, c_char, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, byref, c_char, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 import numpy as np
 
@@ -27,12 +27,21 @@ def _ip(a):
 
 class Engine:
     def __init__(self, feature_size, hidden, num_layers, bidirectional, merge, num_classes, forget_bias=1.0,
-                 learning_rate=1e-4, beta1=0.9, beta2=0.999, epsilon=1e-8, device_id=0, stream=None):
+                 learning_rate=1e-4, beta1=0.9, beta2=0.999, epsilon=1e-8, device_id=0, stream=None,
+                 pre=(), post=0, relu_clip=20.0, dropout=()):
+        """`pre` / `post` / `relu_clip` / `dropout`: the clipped-ReLU dense stages of the DeepSpeech family
+        (networks/deepspeech.py): widths of the stages in front of the LSTM stack, width of the one behind it (0 = none),
+        and the drop probability of each of them in that order."""
         self.lib = _lib.load()
         merge_id = _lib.MERGE_BY_NAME[merge] if isinstance(merge, str) else int(merge)
+        pre, dropout = tuple(int(w) for w in pre), tuple(float(p) for p in dropout)
+        if len(pre) > 3 or len(dropout) > 4:
+            raise ValueError('at most 3 dense stages before the LSTM stack and one behind it')
         self.cfg = _lib.ModelCfg(int(feature_size), int(hidden), int(num_layers), int(bool(bidirectional)), merge_id,
                                  int(num_classes), float(forget_bias), float(learning_rate), float(beta1),
-                                 float(beta2), float(epsilon))
+                                 float(beta2), float(epsilon), len(pre), (c_int32 * 3)(*(pre + (0,) * (3 - len(pre)))),
+                                 int(post), float(relu_clip),
+                                 (c_float * 4)(*[dropout[i] if i < len(dropout) else 0.0 for i in range(4)]))
         if stream is not None and int(stream) == 0:
             raise ValueError('stream 0 (the legacy default stream) cannot carry the engine: pass a created stream '
                              '(e.g. torch.cuda.Stream().cuda_stream) or None for an engine-owned one')
@@ -274,6 +283,16 @@ class Engine:
 
     def set_graph_mode(self, on):
         self._ck(self.lib.nasr_set_graph_mode(self.h, int(bool(on))))
+
+    def set_dropout_state(self, seed, counter):
+        """Pins the keep-masks of the dense stages: forward pass number `counter` of stream `seed` (every forward pass
+        uses the current counter, then increments it)."""
+        self._ck(self.lib.nasr_set_dropout_state(self.h, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF))
+
+    def dropout_state(self):
+        s, c = c_uint32(), c_uint32()
+        self._ck(self.lib.nasr_get_dropout_state(self.h, byref(s), byref(c)))
+        return int(s.value), int(c.value)
 
     @property
     def recurrence_mode(self):

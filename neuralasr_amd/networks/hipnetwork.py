@@ -69,16 +69,23 @@ class HipNetwork(Network):
             torch.cuda.set_stream(self._torch_stream)
             stream = self._torch_stream.cuda_stream
         self.logger.info('Initializing network for %s.' % ('training' if fortraining else 'inference'))
-        self.engine = Engine(config.feature_size, self.num_hidden, self.num_layers, self.bidirectional, self.merge,
-                             self.num_classes, learning_rate=config.learningrate, device_id=device, stream=stream)
+        self.engine = self.make_engine(config, device, stream)
         self.engine.set_step_decode(True)
-        self.engine.set_params(_glorot_init(self.engine.tensors(), seed=1))
+        self.engine.set_params(self.initial_params(self.engine.tensors(), seed=1))
         self._grad_tensor = None
         self.global_step = self.config.start_step
         self.load_checkpoint(self.global_step if fortraining else 1, self.config.model_dir)
         if fortraining and self.coll.rank == 0:
             self.write_config()
             self.config.symbols.write(os.path.join(self.config.model_dir, os.path.basename(self.config.sym_file)))
+
+    # the two hooks a model family overrides (DeepSpeech does): how the engine is shaped, how variables start
+    def make_engine(self, config, device, stream):
+        return Engine(config.feature_size, self.num_hidden, self.num_layers, self.bidirectional, self.merge,
+                      self.num_classes, learning_rate=config.learningrate, device_id=device, stream=stream)
+
+    def initial_params(self, tensors, seed):
+        return _glorot_init(tensors, seed)
 
     # ------------------------------------------------------------------ per-model hook
     def create_network(self, features, labels, seq_len, labels_len, num_classes, is_training):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_structs_match_header_layout():
     from neuralasr_amd import _lib
-    assert ctypes.sizeof(_lib.ModelCfg) == 6 * 4 + 5 * 4
+    assert ctypes.sizeof(_lib.ModelCfg) == 6 * 4 + 5 * 4 + (1 + 3 + 1) * 4 + (1 + 4) * 4   # + the dense-stage fields
     assert ctypes.sizeof(_lib.PhaseTimes) == 9 * 4 + 2 * 4
 
 

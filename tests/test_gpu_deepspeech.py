@@ -1,0 +1,118 @@
+"""GPU: the DeepSpeech-1 family (networks/deepspeech.py: clipped-ReLU dense stages with dropout around a BiLSTM,
+BASELINE.json configs[3]) through the C ABI against the fp64 oracle.  The dropout keep-masks are a
+hash of (seed, pass counter, stage, frame, utterance, unit) that the oracle computes identically (TensorFlow's random
+stream cannot be reproduced: parity of the masks themselves is by definition, parity of everything else by comparison).
+Tolerances as in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from oracle import nasr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(spec, lr=1e-3):
+    from neuralasr_amd.engine import Engine
+    return Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
+                  forget_bias=spec.forget_bias, learning_rate=lr, pre=spec.pre, post=spec.post, relu_clip=spec.relu_clip,
+                  dropout=spec.dropout)
+
+
+def rand_params(spec, seed, scale=0.15):
+    rs = np.random.RandomState(seed)
+    return [p + scale * rs.randn(*p.shape) for p in O.init_params(spec, seed=seed)]
+
+
+CASES = [
+    # spec, B, T
+    (O.ModelSpec(20, 24, 1, True, 'concat', 7, pre=(40, 33, 50), post=36, relu_clip=1.0, dropout=(0.2, 0.1, 0.3, 0.25)), 5, 21),
+    (O.ModelSpec(26, 70, 1, True, 'concat', 29, pre=(64, 64, 140), post=64, relu_clip=20.0, dropout=(0.05, 0.05, 0.05, 0.05)), 16, 30),
+    (O.ModelSpec(12, 32, 1, True, 'concat', 6, pre=(48,), post=0, relu_clip=2.0, dropout=(0.5,)), 3, 17),      # one pre stage, no post stage
+    (O.ModelSpec(12, 32, 2, False, 'none', 6, pre=(), post=20, relu_clip=0.7, dropout=(0.4,)), 4, 15),        # post stage only, uni stack
+    (O.ModelSpec(16, 40, 1, True, 'concat', 9, pre=(32, 32, 80), post=32, relu_clip=3.0, dropout=()), 18, 12),  # no dropout
+]
+
+
+def case_id(c):
+    s, B, T = c
+    return f"pre{'x'.join(map(str, s.pre)) or '0'}-H{s.hidden}L{s.num_layers}-post{s.post}-B{B}T{T}"
+
+
+@pytest.mark.parametrize("case", CASES, ids=case_id)
+def test_deepspeech_family_matches_oracle(case):
+    spec, B, T = case
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=3 * B + T, var_len=True, Lmin=1, Lmax=max(1, T // 5))
+    params = rand_params(spec, 4)
+    e = make_engine(spec)
+    names = [n for n, _, _, _ in e.tensors()]
+    assert names == [n for n, _ in spec.param_shapes()]        # creation order of networks/deepspeech.py
+    assert e.param_count == spec.param_count()
+    e.set_params(O.flatten(params))
+    np.testing.assert_array_equal(e.get_params(), O.flatten(params).astype(np.float32))
+
+    seed, counter = 4567, 11
+    loss_o, nll_o, grads_o, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len,
+                                                                drop=(seed, counter))
+    e.set_dropout_state(seed, counter)
+    logits = e.forward(feats, seq_len)
+    assert e.dropout_state() == (seed, counter + 1)            # every forward pass draws new masks
+    np.testing.assert_allclose(logits, logits_o, atol=1e-4)
+    e.set_dropout_state(seed, counter)
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert loss == pytest.approx(loss_o, rel=2e-5)
+    np.testing.assert_allclose(nll, nll_o, rtol=2e-5)
+    scale = np.linalg.norm(O.flatten(grads_o))
+    for (name, off, r, c), g_o in zip(e.tensors(), grads_o):
+        g = grads[off:off + r * c].reshape(g_o.shape)
+        assert np.linalg.norm(g - g_o) <= 1e-4 * np.linalg.norm(g_o) + 1e-6 * scale, name
+    if any(spec.drop_p(i) > 0 for i in range(4)):
+        logits2 = e.forward(feats, seq_len)                    # counter moved on: other masks, other logits
+        assert np.abs(logits2 - logits).max() > 1e-3
+    e.close()
+
+
+def test_deepspeech_training_step_matches_oracle_adam():
+    spec = O.ModelSpec(14, 20, 1, True, 'concat', 6, pre=(24, 24, 40), post=24, relu_clip=2.0, dropout=(0.1, 0.1, 0.1, 0.1))
+    B, T = 4, 14
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=8, var_len=True, Lmin=1, Lmax=3)
+    params = rand_params(spec, 6)
+    e = make_engine(spec, lr=1e-2)
+    e.set_params(O.flatten(params))
+    e.set_dropout_state(99, 0)
+    st = O.AdamState(params) if hasattr(O, 'AdamState') else None
+    losses = []
+    p = [q.copy() for q in params]
+    m = [np.zeros_like(q) for q in p]
+    v = [np.zeros_like(q) for q in p]
+    for step in range(3):
+        losses.append(e.train_step(feats, seq_len, labels, label_len))
+        loss_o, _, g, _ = O.network_loss_and_grads(spec, p, feats, seq_len, labels, label_len, drop=(99, step))
+        assert losses[-1] == pytest.approx(loss_o, rel=5e-5)
+        t = step + 1
+        lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        for k in range(len(p)):
+            m[k] = 0.9 * m[k] + 0.1 * g[k]
+            v[k] = 0.999 * v[k] + 0.001 * g[k] * g[k]
+            p[k] = p[k] - lr_t * m[k] / (np.sqrt(v[k]) + 1e-8)
+    got = e.get_params()
+    np.testing.assert_allclose(got, O.flatten(p), rtol=0, atol=5e-4)
+    e.close()
+
+
+def test_reference_shape_constructs_and_steps():
+    """networks/deepspeech.py at its own sizes (n_hidden 2048, BiLSTM 2048, 26-MFCC x 21 context), a short batch:
+    the per-step recurrence kernels serve Hp = 2048 (no persistent instantiation), loss finite and decreasing."""
+    from neuralasr_amd.networks.deepspeech import DeepSpeech
+    spec = O.ModelSpec(546, DeepSpeech.n_cell_dim, 1, True, 'concat', 29, pre=DeepSpeech.pre_widths(), post=DeepSpeech.n_hidden,
+                       relu_clip=DeepSpeech.relu_clip, dropout=DeepSpeech.dropout)
+    B, T = 4, 24
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1, Lmin=2, Lmax=4)
+    e = make_engine(spec, lr=1e-4)
+    assert e.recurrence_mode == 'per-step'
+    rs = np.random.RandomState(0)
+    e.set_params((rs.randn(e.param_count) * 0.02).astype(np.float32))
+    l0 = e.train_step(feats, seq_len, labels, label_len)
+    l1 = e.train_step(feats, seq_len, labels, label_len)
+    l2 = e.train_step(feats, seq_len, labels, label_len)
+    assert np.isfinite([l0, l1, l2]).all() and l2 < l0
+    e.close()

@@ -29,7 +29,7 @@ CASES = [
     (O.ModelSpec(13, 128, 1, False, 'none', 6), 4, 60),           # 128  config 1 of BASELINE.json (lstm_ctc_net 1x128)
     (O.ModelSpec(20, 200, 2, True, 'concat', 11), 19, 24),        # 256  NU 8, 2 rounds (Bp 32), 2 layers
     (O.ModelSpec(26, 500, 1, True, 'stack_reshape', 29), 16, 48),  # 512  the literal BiLstmCTCNet width
-    (O.ModelSpec(12, 300, 1, False, 'none', 7), 40, 18),          # 512 (padded from 300) uni, Bp 48: 2 rounds of 8 x 4
+    (O.ModelSpec(12, 460, 1, False, 'none', 7), 40, 18),          # 512 (padded from 460) uni, Bp 48: 2 rounds of 8 x 4
     (O.ModelSpec(12, 120, 3, False, 'none', 9), 3, 90),           # 128  3-layer uni stack, B 3
 ]
 
@@ -96,7 +96,9 @@ def test_training_steps_agree_between_modes():
         e.close()
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=5e-6)
     assert out[0][0][-1] < out[0][0][0]
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=2e-6)
+    # Adam divides by sqrt(v): where a gradient is ~0 its fp32 rounding differences are amplified up to the step size
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=5e-5)
+    assert (np.abs(out[0][1] - out[1][1]) > 2e-6).mean() < 1e-3
 
 
 def test_unsupported_width_uses_per_step_kernels():
