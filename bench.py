@@ -32,6 +32,9 @@ def workload_spec(name):
         return ModelSpec(546, 500, 1, True, 'stack_reshape', 29), 'bilstm_ctc_net literal 1x500 bi stack_reshape'
     if name == 'lstm3':
         return ModelSpec(546, 500, 3, False, 'none', 29), 'lstm_ctc_net 3x500 uni'
+    if name == 'deepspeech':     # BASELINE.json configs[3]: networks/deepspeech.py at its own sizes, batch 32 per GPU
+        return (ModelSpec(546, 2048, 1, True, 'concat', 29, pre=(2048, 2048, 4096), post=2048, relu_clip=20.0,
+                          dropout=(0.05, 0.05, 0.05, 0.05)), 'deepspeech (3 dense + BiLSTM 2048 + dense), dropout 0.05')
     return ModelSpec(546, 500, 3, True, 'concat', 29), 'bilstm_ctc_net 3x500 bi concat'
 
 
@@ -46,6 +49,13 @@ def algorithmic_bytes(spec, B, T):
         A += 4 * N * (I + 6 * D * H + 15 * D * H + I + (I if l > 0 else 0))
     rows = 2 if (spec.bidirectional and spec.merge == 'stack_reshape') else 1
     A += 16 * N * C * rows
+    # dense stages: forward reads the input and writes the output; backward reads dY, Y, writes dZ, re-reads input and dZ
+    # for the weight gradient and writes the input gradient
+    widths = [(spec.feature_size if i == 0 else spec.pre[i - 1], w) for i, w in enumerate(spec.pre)]
+    if spec.post:
+        widths.append((spec.proj_in, spec.post))
+    for i_w, o_w in widths:
+        A += 4 * N * (i_w + o_w + 3 * o_w + i_w + o_w + i_w)
     W = 40 * spec.param_count()
     R = 2 * T * sum(D * 4 * H * H * 4 for _ in range(spec.num_layers))
     return A, W, R
@@ -70,6 +80,8 @@ def cpu_baseline(spec, B, seed):
     timed call takes ~10-20 s.  Falls back to the fp64 NumPy oracle if the C library cannot be built."""
     from oracle import nasr_oracle as O
     try:
+        if spec.deepspeech:
+            raise RuntimeError('the C restatement covers the (Bi)LSTM-CTC nets only')
         from oracle import cref
         cref.set_threads(cref.usable_cpus())           # honour the container's CPU quota
         threads = cref.num_threads()
@@ -98,7 +110,7 @@ def cpu_baseline(spec, B, seed):
         thr = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
     except Exception:
         thr = os.cpu_count() or 1
-    Tc = 200 if spec.num_layers > 1 else 400
+    Tc = 24 if spec.deepspeech else (200 if spec.num_layers > 1 else 400)
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, Tc, seed=seed)
     params = O.init_params(spec, seed=1)
     t0 = time.time()
@@ -114,8 +126,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='bilstm3x500', choices=['bilstm3x500', 'literal', 'lstm3'])
-    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--workload', default='bilstm3x500', choices=['bilstm3x500', 'literal', 'lstm3', 'deepspeech'])
+    ap.add_argument('--batch', type=int, default=None, help='utterances per GPU (16; 32 for deepspeech)')
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--var-len', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -143,7 +155,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     spec, wname = workload_spec(args.workload)
-    B, T = args.batch, args.frames
+    B, T = args.batch or (32 if args.workload == 'deepspeech' else 16), args.frames
     # One explicit (non-default) torch stream carries everything: the engine launches on it and torch.distributed
     # orders its RCCL work against the CURRENT stream, so kernels -> all-reduce -> Adam need no host sync.
     # (The legacy default stream cannot be used: it is not capturable and an engine-owned stream would not be
@@ -152,7 +164,8 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     eng = Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
-                 learning_rate=1e-4, device_id=local, stream=stream)
+                 learning_rate=1e-4, device_id=local, stream=stream, pre=spec.pre, post=spec.post,
+                 relu_clip=spec.relu_clip, dropout=spec.dropout)
     eng.set_graph_mode(not args.no_graph)
     if args.per_step:
         eng.set_recurrence_mode(False)
@@ -228,7 +241,7 @@ def main():
             except Exception:
                 pmc = None
         out = {
-            'metric': 'audio-frames/sec (fwd+bwd+CTC+Adam) at batch 16 per GPU',
+            'metric': f'audio-frames/sec (fwd+bwd+CTC+Adam) at batch {B} per GPU',
             'value': total_frames * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

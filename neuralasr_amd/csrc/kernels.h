@@ -79,7 +79,8 @@ void launch_expand_context(const float* centre, const float* pad, const int* seq
 void launch_repack_u(const float* U, float* Uf, float* Ub, int Hp, hipStream_t st);
 void launch_lstm_fwd_step(const LstmDims& dm, int s, const float* Uf, const float* hin, float* hout, float* gates,
                           float* cbuf, float* out, const int* seq_len, float forget_bias, hipStream_t st);
-// BPTT step: pin/pout = [D][Hp/32][Bp][Hp] partial sums handed launch to launch, dcin/dcout = [D][Bp][Hp]
+// BPTT step: pin/pout = [D][lstm_bwd_partials(Hp)][Bp][Hp] partial sums handed launch to launch, dcin/dcout = [D][Bp][Hp]
+int lstm_bwd_partials(int Hp);
 void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const float* pin, float* pout,
                           const float* gates, float* dgbuf, const float* cbuf, const float* dout, const float* dcin,
                           float* dcout, const int* seq_len, hipStream_t st);

@@ -311,7 +311,12 @@ void launch_lstm_fwd_step(const LstmDims& dm, int s, const float* Uf, const floa
 //   G: partial_out[ks][b][64jt..] = dG_slice x U^T tile on v_mfma_f32_16x16x4 (wave w = gate w),
 //      4-wave LDS reduction, plain stores.  The next launch sums the KSPLIT partials in fixed order.
 // Masked frames get dG = 0 so the GEMMs need no mask.
-template <int MT, int KSP>
+// Wide layers (Hp > 512, e.g. DeepSpeech's 2048): every output tile's block would re-sum the same Hp/32 partials
+// (Hp^3 traffic: 434 us per step at Hp = 2048).  There the step is two launches: lstm_bwd_cell_kernel sums the partials
+// and does the cell arithmetic ONCE per cell (writing dG frame-indexed), and this kernel runs with PRE = true: its P
+// stage only copies its dG slice from that buffer, and each block walks KSL = 4 consecutive K slices with the
+// accumulators kept in registers, so 4x fewer partial sums are handed on.
+template <int MT, int KSP, bool PRE = false, int KSL = 1>
 __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
     const float* __restrict__ Ub,     // [D][Hp/64][Hp/32][4][4][2][64][4]
     const float* __restrict__ pin,    // [D][KSPLIT][Bp][Hp] partial sums of dh_rec from the previous launch
@@ -323,10 +328,19 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
   __shared__ __attribute__((aligned(16))) float As[MT][128][17];
   __shared__ __attribute__((aligned(16))) float red[4][MT][4][64][4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int KSPLIT = KSP > 0 ? KSP : (Hp >> 5);
-  const int jt = blockIdx.x / KSPLIT, ks = blockIdx.x % KSPLIT, d = blockIdx.y;
+  const int KSPLIT = KSP > 0 ? KSP : (Hp >> 5);     // K slices of 32 units in the operand image
+  const int NKG = KSPLIT / KSL;                      // K-slice groups = partial sums per output
+  const int jt = blockIdx.x / NKG, ksg = blockIdx.x % NKG, d = blockIdx.y;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  for (int kl = 0; kl < KSL; ++kl) {
+  const int ks = ksg * KSL + kl;
+  if (KSL > 1 && kl > 0) __syncthreads();            // the previous slice's fragment reads of As are done
   // ---- this wave's 8 B-operand fragments (32 KB per block), in flight during the P stage
   const float4* ub = reinterpret_cast<const float4*>(Ub) +
                      ((((size_t)(d * (Hp >> 6) + jt) * KSPLIT + ks) * 4 + w) * 8) * 64 + lane;
@@ -340,6 +354,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
   // of its arithmetic so the two latency chains overlap.
   const float* pbase = pin + (size_t)d * KSPLIT * Bp * Hp;
   constexpr int KV = KSP > 0 ? KSP : 1;
+  if constexpr (PRE) {
+#pragma unroll
+    for (int cp = 0; cp < 2 * MT; ++cp) {
+      const int c = tid + 256 * cp;
+      const int ju = c & 31, b = c >> 5;
+      const int mt = b >> 4, b16 = b & 15;
+      const int len = seq_len[b];
+      const int tb = s < len ? (d ? (len - 1 - s) : s) : s;
+      const float4 dg = *reinterpret_cast<const float4*>(dgbuf + ((size_t)tb * Bp + b) * DN + d * N4 + 4 * (32 * ks + ju));
+      As[mt][0 * 32 + ju][b16] = dg.x;
+      As[mt][1 * 32 + ju][b16] = dg.y;
+      As[mt][2 * 32 + ju][b16] = dg.z;
+      As[mt][3 * 32 + ju][b16] = dg.w;
+    }
+  } else {
 #pragma unroll
   for (int cp2 = 0; cp2 < MT; ++cp2) {
     int lenv[2];
@@ -408,14 +437,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
       As[mt][3 * 32 + ju][b16] = dg.w;
     }
   }
+  }   // !PRE
   __syncthreads();
 
   // ---- G stage: wave w contracts k_local in [32w, 32w+32) (gate w) for the 4 N-tiles
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q2 = 0; q2 < 2; ++q2) {
 #pragma unroll
@@ -432,6 +457,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
       }
     }
   }
+  }   // K-slice loop
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -439,7 +465,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
   __syncthreads();
 
   // ---- wave w finalises N-tile w: C/D map col = lane&15 (unit), row = 4*(lane>>4)+reg (batch row)
-  float* po = pout + ((size_t)d * KSPLIT + ks) * Bp * Hp;
+  float* po = pout + ((size_t)d * NKG + ksg) * Bp * Hp;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][m][w][lane][0]) +
@@ -453,11 +479,71 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
   }
 }
 
+// one thread per cell (b, j) of direction d: dh = sum of the NP partial sums + dOut, gate derivatives, dc; writes the
+// frame-indexed dG row (zero at masked frames) and the carried dc
+__global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(const float* __restrict__ pin, int NP,
+                                                            const float* __restrict__ gates, float* __restrict__ dgbuf,
+                                                            const float* __restrict__ cbuf, const float* __restrict__ dout,
+                                                            const float* __restrict__ dcin, float* __restrict__ dcout,
+                                                            const int* __restrict__ seq_len, int s, int Bp, int Hp, int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+  if (c >= Bp * Hp) return;
+  const int j = c % Hp, b = c / Hp;
+  const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
+  const int len = seq_len[b];
+  const bool val = s < len;
+  const int tb = val ? (d ? (len - 1 - s) : s) : s;
+  const size_t r = (size_t)tb * Bp + b;
+  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dcn = 0.f;
+  if (val) {
+    const float* pp = pin + (size_t)d * NP * Bp * Hp + (size_t)b * Hp + j;
+    float dhs = dout[r * DH + d * Hp + j];
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < NP; k += 2) { s0 += pp[(size_t)k * Bp * Hp]; s1 += pp[(size_t)(k + 1) * Bp * Hp]; }
+    if (k < NP) s0 += pp[(size_t)k * Bp * Hp];
+    dhs += s0 + s1;
+    const float4 a = *reinterpret_cast<const float4*>(gates + r * DN + d * N4 + 4 * j);
+    const float cc = cbuf[r * DH + d * Hp + j];
+    const float cpv = s > 0 ? cbuf[(d ? r + Bp : r - Bp) * DH + d * Hp + j] : 0.f;
+    const float tc = tanhf_(cc);
+    const float dct = dcin[((size_t)d * Bp + b) * Hp + j] + dhs * a.w * (1.f - tc * tc);
+    dg.x = dct * a.y * a.x * (1.f - a.x);
+    dg.y = dct * a.x * (1.f - a.y * a.y);
+    dg.z = dct * cpv * a.z * (1.f - a.z);
+    dg.w = dhs * tc * a.w * (1.f - a.w);
+    dcn = dct * a.z;
+  }
+  *reinterpret_cast<float4*>(dgbuf + r * DN + d * N4 + 4 * j) = dg;
+  dcout[((size_t)d * Bp + b) * Hp + j] = dcn;
+}
+
+// partial sums a BPTT step hands on: Hp/32 of them per output, Hp/128 for the wide-layer form
+int lstm_bwd_partials(int Hp) { return Hp > 512 ? Hp / 128 : Hp / 32; }
+
 void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const float* pin, float* pout,
                           const float* gates, float* dgbuf, const float* cbuf, const float* dout, const float* dcin,
                           float* dcout, const int* seq_len, hipStream_t st) {
-  dim3 grid((dm.Hp / 64) * (dm.Hp / 32), dm.D), block(256);
   const int MT = dm.Bp / 16, ksp = dm.Hp / 32;
+  if (dm.Hp > 512 && dm.Hp % 128 == 0) {     // wide layer: cell arithmetic once, then the product (see the kernel's header)
+    const int np = dm.Hp / 128;
+    hipLaunchKernelGGL(lstm_bwd_cell_kernel, dim3((dm.Bp * dm.Hp + 255) / 256, dm.D), dim3(256), 0, st, pin, np, gates, dgbuf,
+                       cbuf, dout, dcin, dcout, seq_len, s, dm.Bp, dm.Hp, dm.D);
+    dim3 gridw((dm.Hp / 64) * np, dm.D);
+#define NASR_BWDW(MTV)                                                                                              \
+  hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV, 0, true, 4>), gridw, dim3(256), 0, st, Ub, pin, pout, gates, dgbuf, cbuf, \
+                     dout, dcin, dcout, seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D)
+    switch (MT) {
+      case 1: NASR_BWDW(1); break;
+      case 2: NASR_BWDW(2); break;
+      case 3: NASR_BWDW(3); break;
+      default: NASR_BWDW(4); break;
+    }
+#undef NASR_BWDW
+    return;
+  }
+  dim3 grid((dm.Hp / 64) * (dm.Hp / 32), dm.D), block(256);
 #define NASR_BWD(MTV, KV)                                                                                        \
   hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV, KV>), grid, block, 0, st, Ub, pin, pout, gates, dgbuf, cbuf, \
                      dout, dcin, dcout, seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D)

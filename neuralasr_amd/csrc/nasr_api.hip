@@ -622,7 +622,7 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
   }
   const size_t sU = (size_t)l * h->D * h->Hp * h->N4;
   const size_t hs = (size_t)h->D * h->Bp * h->Hp;   // one h-state image
-  const size_t ps = (size_t)h->D * (h->Hp / 32) * h->Bp * h->Hp;   // one partial-sum image
+  const size_t ps = (size_t)h->D * lstm_bwd_partials(h->Hp) * h->Bp * h->Hp;   // one partial-sum image
   float* hst = h->hstateL[lidx(h, l)].as<float>();
   float* par = h->partialL[lidx(h, l)].as<float>();
   float* dcs = h->dcstateL[lidx(h, l)].as<float>();

@@ -117,3 +117,23 @@ def test_unsupported_width_uses_per_step_kernels():
     loss, _, _ = e.loss_and_grads(feats, seq_len, labels, label_len)
     assert loss == pytest.approx(loss_o, rel=2e-5)
     e.close()
+
+
+def test_wide_layer_uses_the_two_launch_bptt_step():
+    """Hp = 640 > 512: the BPTT step is lstm_bwd_cell_kernel (cell arithmetic once per cell) + the product kernel
+    walking 4 K slices per block (lstm.hip); DeepSpeech's 2048-wide BiLSTM runs on this form."""
+    spec = O.ModelSpec(9, 600, 1, True, 'concat', 6)
+    B, T = 18, 7                                            # Bp = 32: two M tiles
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=21, var_len=True, Lmin=1, Lmax=2)
+    params = rand_params(spec, 9)
+    e = make_engine(spec)
+    assert e.recurrence_mode == 'per-step'
+    e.set_params(O.flatten(params))
+    loss_o, nll_o, grads_o, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert loss == pytest.approx(loss_o, rel=2e-5)
+    scale = np.linalg.norm(O.flatten(grads_o))
+    for (name, off, r, c), g_o in zip(e.tensors(), grads_o):
+        g = grads[off:off + r * c].reshape(g_o.shape)
+        assert np.linalg.norm(g - g_o) <= 1e-4 * np.linalg.norm(g_o) + 1e-6 * scale, name
+    e.close()
