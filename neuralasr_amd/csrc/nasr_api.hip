@@ -175,6 +175,8 @@ namespace {
 
 // A persistent launch that gave up (bounded spin, unexpected placement) leaves its outputs undefined: surface it at
 // the next host sync and use the per-step kernels from then on.
+int repack(nasr_ctx* h);
+
 int persist_check(nasr_ctx* h) {
   if (!h->persist_used) return NASR_OK;
   h->persist_used = false;
@@ -183,6 +185,7 @@ int persist_check(nasr_ctx* h) {
   *reinterpret_cast<volatile unsigned*>(h->perr) = 0;
   h->persist = false;
   h->persist_ok = false;
+  (void)repack(h);   // operand images of the per-step kernels
   return h->fail(NASR_ERR_HIP, "persistent recurrence aborted (code " + std::to_string(code) +
                                    ": 1 = hand-off timeout, 2 = workgroup placement); the results of this step are "
                                    "invalid, later steps use the per-step kernels");
@@ -385,8 +388,9 @@ int repack(nasr_ctx* h) {
     for (int d = 0; d < h->D; ++d) {
       const size_t k = (size_t)l * h->D + d;
       const size_t o = k * (size_t)h->Hp * h->N4;
-      launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
+      // only the operand images of the kernels in use (a mode switch calls repack again)
       if (h->persist) launch_repack_persist(h->P + h->off_u[k], h->Upf + k * h->imf, h->Upb + k * h->imb, h->Hp, h->st);
+      else launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
     }
   if (h->gemm_tp) {
     for (int l = 0; l < h->L; ++l) {
@@ -1695,8 +1699,7 @@ int nasr_set_recurrence_mode(nasr_handle h, int persistent) {
     return h->fail(NASR_ERR_STATE, "the persistent recurrence is not available on this device / hidden size");
   HIPCHK(h, hipStreamSynchronize(h->st));
   h->persist = persistent != 0;
-  if (h->persist) return repack(h);
-  return NASR_OK;
+  return repack(h);
 }
 
 }  // extern "C"
