@@ -186,3 +186,37 @@ def test_rccl_path_at_world_one_orders_with_the_engine_stream(tmp_path):
     finally:
         torch.cuda.set_stream(torch.cuda.default_stream())
         dist.destroy_process_group()
+
+
+def test_deepspeech_plugin_trains_and_validates(tmp_path, monkeypatch):
+    """`network=networks.deepspeech.DeepSpeech` resolves to the HIP class (reference: networks/deepspeech.py); run at
+    reduced widths so the toy set trains in a blink: variable names / shapes in the reference's creation order, initial
+    values per its initialisers, loss falls, validate() and decode() work, checkpoints round-trip."""
+    from neuralasr_amd.networks import deepspeech as ds_mod
+    monkeypatch.setattr(ds_mod.DeepSpeech, 'n_hidden', 48)
+    monkeypatch.setattr(ds_mod.DeepSpeech, 'n_cell_dim', 40)
+    cfg = Config(make_config(tmp_path, network='networks.deepspeech.DeepSpeech', num_gpus='1', learningrate='0.002'), True)
+    net = cfg.load_network(fortraining=True)
+    assert type(net).__name__ == 'DeepSpeech' and net.engine.recurrence_mode == 'persistent'
+    names = [n for n, _, _, _ in net.engine.tensors()]
+    assert names == ['b1', 'h1', 'b2', 'h2', 'b3', 'h3', 'l0/fw/kernel', 'l0/fw/bias', 'l0/bw/kernel', 'l0/bw/bias',
+                     'b5', 'h5', 'b6', 'h6']
+    shapes = {n: (r, c) for n, _, r, c in net.engine.tensors()}
+    F, C = cfg.feature_size, cfg.symbols.counter
+    assert shapes['h1'] == (F, 48) and shapes['h3'] == (48, 80) and shapes['l0/fw/kernel'] == (80 + 40, 160)
+    assert shapes['h5'] == (80, 48) and shapes['h6'] == (48, C)
+    p0 = net.engine.get_params()
+    off = {n: o for n, o, _, _ in net.engine.tensors()}
+    assert abs(p0[off['h2']:off['h2'] + 48 * 48].std() - 0.046875) < 0.01          # N(0, stddev) (deepspeech.py:25,56)
+    assert np.all(p0[off['l0/fw/bias']:off['l0/fw/bias'] + 160] == 0)
+    ds = DataSet(cfg.train_input, cfg)
+    mfccs, labels, seq_len, labels_len = ds.get_next_batch()
+    losses = [float(net.train(mfccs, labels, seq_len, labels_len)[0]) for _ in range(8)]
+    assert np.isfinite(losses).all() and min(losses[-3:]) < losses[0]
+    assert net.global_step == 8 and net.engine.dropout_state() == (4567, 8)
+    vl = net.validate(mfccs, labels, seq_len, labels_len)
+    assert np.isfinite(vl[0])
+    net.save_checkpoint()
+    assert glob.glob(os.path.join(cfg.model_dir, 'model-8.npz'))
+    ids = net.decode(mfccs[:1], seq_len[:1])
+    assert ids.ndim == 1
