@@ -205,6 +205,28 @@ def main():
         total_frames = float(frames)
     loss = eng.get_loss()
 
+    # ---- the same step fed from host buffers (features cross PCIe every step): never `value`, reported beside it
+    NH = 5
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(NH):
+        eng.upload_batch(feats, seq_len, labels, label_len)
+        step()
+    fence()
+    dt_h2d = (time.perf_counter() - t1) / NH
+    # ---- the gradient all-reduce alone (time per step and bus bandwidth), N > 1 only
+    ar_ms = None
+    if use_dist and world > 1:
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+        fence()
+        ar = torch.tensor([(time.perf_counter() - t2) / 10], device='cuda', dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        ar_ms = float(ar.item()) * 1e3
+        gt.zero_()            # the summed buffer is not a gradient any more; the next compute_grads overwrites it
+
     # ---- per-phase / per-launch timing with HIP events on the engine's stream (a few extra steps)
     eng.set_profiling(True)
     acc = None
@@ -260,7 +282,14 @@ def main():
                               'achieved': (A + W + R) / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': (A + W + R) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             'phases_ms': {k: round(v, 4) for k, v in phases.items() if k.endswith('_ms')},
+            'incl_h2d': {'ms_per_step': dt_h2d * 1e3, 'value': float(frames) * world / dt_h2d, 'unit': 'frames/s',
+                         'note': 'features uploaded from host memory every step (PCIe-inclusive); rank-0 clock'},
         }
+        if ar_ms is not None:
+            gbytes = gt.numel() * 4 / 1e9
+            out['allreduce'] = {'ms': ar_ms, 'bytes': gt.numel() * 4,
+                                'bus_GBps': 2.0 * (world - 1) / world * gbytes / (ar_ms * 1e-3),
+                                'xgmi_peak_GBps': 7 * 153.0}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, B, 1234)
         else:
