@@ -1,5 +1,6 @@
 """Host logic around the hot path that needs no GPU: the training loop's cadence and log lines
 (reference: train.py:14-47) with a stub network, greedy-collapse / LER helper in the C library (host code)."""
+import ctypes
 import logging
 import os
 
@@ -10,6 +11,8 @@ from neuralasr_amd import train as train_mod
 from neuralasr_amd.config import Config
 from neuralasr_amd.dataset import DataSet
 from oracle import nasr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SAMPLES = os.path.join(HERE, 'golden', 'sample_set')
@@ -91,3 +94,50 @@ def test_label_error_rate_host_function_matches_oracle():
     lib.nasr_label_error_rate(ids.ctypes.data_as(ip), lens.ctypes.data_as(ip), 9, labels.ctypes.data_as(ip),
                               label_len.ctypes.data_as(ip), Lmax, B, ctypes.byref(out))
     assert np.isinf(out.value)
+
+
+def test_deepspeech_class_mirrors_the_reference_locals():
+    """networks/deepspeech.py:15-26: widths, clip, stddev, seed; dropout of layers 1, 2, 3 and 5 (the two cell entries
+    of the reference's list are 0.0 = no DropoutWrapper effect)."""
+    from neuralasr_amd.networks.deepspeech import DeepSpeech
+    assert DeepSpeech.n_hidden == 2048 and DeepSpeech.n_cell_dim == 2048
+    assert DeepSpeech.pre_widths() == (2048, 2048, 4096)              # n_hidden_1, n_hidden_2, n_hidden_3 = 2*n_cell_dim
+    assert DeepSpeech.relu_clip == 20.0 and DeepSpeech.stddev == 0.046875 and DeepSpeech.random_seed == 4567
+    assert DeepSpeech.dropout == (0.05, 0.05, 0.05, 0.05)
+    assert DeepSpeech.bidirectional and DeepSpeech.merge == 'concat' and DeepSpeech.num_layers == 1
+    # initial values per the reference's initialisers, on a toy tensor list (name, offset, rows, cols)
+    tensors = [('b1', 0, 8, 1), ('h1', 8, 6, 8), ('h2', 56, 8, 8), ('l0/fw/kernel', 120, 12, 16), ('l0/fw/bias', 312, 16, 1),
+               ('b6', 328, 5, 1), ('h6', 333, 8, 5)]
+    net = DeepSpeech.__new__(DeepSpeech)
+    p = net.initial_params(tensors, seed=3)
+    assert p.dtype == np.float32 and p.size == 373
+    assert np.all(p[312:328] == 0)                                    # cell bias: zeros (TF default)
+    lim = np.sqrt(6.0 / (12 + 16))
+    assert np.abs(p[120:312]).max() <= lim                            # cell kernel: glorot-uniform (TF default)
+    assert 0 < np.abs(p[0:8]).max() < 0.3                             # b1 ~ N(0, stddev)
+
+
+def test_engine_packs_the_dense_stage_fields():
+    """ctypes layout of the DeepSpeech fields of nasr_model_cfg (include/nasr.h) as Engine fills them."""
+    from neuralasr_amd import _lib
+    cfg = _lib.ModelCfg(546, 2048, 1, 1, 2, 29, 1.0, 1e-4, 0.9, 0.999, 1e-8, 3, (ctypes.c_int32 * 3)(2048, 2048, 4096), 2048,
+                        20.0, (ctypes.c_float * 4)(0.05, 0.05, 0.05, 0.05))
+    raw = bytes(cfg)
+    ints = np.frombuffer(raw[44:44 + 20], np.int32)                   # after 6 int32 + 5 float
+    assert ints.tolist() == [3, 2048, 2048, 4096, 2048]
+    fl = np.frombuffer(raw[64:64 + 20], np.float32)
+    assert fl.tolist() == pytest.approx([20.0, 0.05, 0.05, 0.05, 0.05])
+
+
+def test_bench_algorithmic_bytes_cover_the_dense_stages():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s3, _ = bench.workload_spec('bilstm3x500')
+    A, W, R = bench.algorithmic_bytes(s3, 16, 500)
+    assert (A, W, R) == (2246656000, 40 * s3.param_count(), 24000000000)          # SURVEY.md §8d: 2 247 MB, 649 MB, 24 000 MB
+    sd, name = bench.workload_spec('deepspeech')
+    assert sd.pre == (2048, 2048, 4096) and sd.post == 2048 and 'deepspeech' in name
+    Ad, Wd, Rd = bench.algorithmic_bytes(sd, 32, 500)
+    assert Ad > A and Wd == 40 * sd.param_count() and Rd == 2 * 500 * 2 * 4 * 2048 * 2048 * 4
