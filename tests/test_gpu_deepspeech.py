@@ -30,6 +30,10 @@ CASES = [
     (O.ModelSpec(12, 32, 1, True, 'concat', 6, pre=(48,), post=0, relu_clip=2.0, dropout=(0.5,)), 3, 17),      # one pre stage, no post stage
     (O.ModelSpec(12, 32, 2, False, 'none', 6, pre=(), post=20, relu_clip=0.7, dropout=(0.4,)), 4, 15),        # post stage only, uni stack
     (O.ModelSpec(16, 40, 1, True, 'concat', 9, pre=(32, 32, 80), post=32, relu_clip=3.0, dropout=()), 18, 12),  # no dropout
+    # the reference's proportions at 1/8 width (n_hidden 256, cells 256, layer 3 = 512), 26 MFCC x 21 context, its own
+    # dropout and clip: several GEMM tiles per stage, split-K weight gradients, the persistent recurrence at Hp 256
+    (O.ModelSpec(546, 256, 1, True, 'concat', 29, pre=(256, 256, 512), post=256, relu_clip=20.0,
+                 dropout=(0.05, 0.05, 0.05, 0.05)), 8, 60),
 ]
 
 
