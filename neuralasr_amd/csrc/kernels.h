@@ -98,13 +98,14 @@ size_t persist_xch_floats(int Hp);               // floats of the exchange buffe
 hipError_t persist_prepare();                    // once per process: raise the kernels' dynamic-LDS limit
 void launch_repack_persist(const float* U, float* Upf, float* Upb, int Hp, hipStream_t st);
 // Upf/Upb: [D] images of this layer; xch: persist_xch_floats(Hp) floats; ctl: one PersistCtl (zeroed by the launcher);
-// sticky: host-mapped word that receives the error code of an aborted launch (or NULL)
+// sticky: host-mapped word that receives the error code of an aborted launch (or NULL); fault: device float set to 1
+// by an aborted launch (or NULL) - the engine keeps it behind the gradients so that it is all-reduced with them
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates, float* cbuf, float* out,
-                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float forget_bias,
-                             hipStream_t st);
+                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
+                             float forget_bias, hipStream_t st);
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
-                             hipStream_t st);
+                             float* fault, hipStream_t st);
 
 // ---- DeepSpeech dense stages (dense.hip): clipped ReLU + hash-defined dropout, in place ----
 void launch_dense_act(float* z, int R, int Bp, int B, int W, int ld, float clip, float p, uint32_t seed, uint32_t counter,
@@ -131,8 +132,9 @@ void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, in
                    hipStream_t st);
 
 // ---- optimiser / reductions (optim.hip) ----
+// fault: device word (or NULL); a non-zero value makes the launch a no-op (see optim.hip)
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr_t, float beta1, float beta2,
-                 float eps, float gscale, hipStream_t st);
+                 float eps, float gscale, const float* fault, hipStream_t st);
 // out[n] = sum_r M[r*ld + n], deterministic two-stage; ws holds 32*N floats
 void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st);
 void launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, hipStream_t st);

@@ -32,6 +32,7 @@
 // PersistCtl::error, the launch drains, and the host falls back to the per-step kernels of lstm.hip for good.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -98,12 +99,14 @@ __device__ __forceinline__ bool poll_ge(gu32* p, bool active, unsigned want) {
 }
 
 // (xcc id, ticket within the XCD) of this workgroup; false when the placement is not 32-per-XCD-of-8
-__device__ __forceinline__ void raise_error(PersistCtl* ctl, unsigned* sticky, unsigned code) {
+__device__ __forceinline__ void raise_error(PersistCtl* ctl, unsigned* sticky, float* fault, unsigned code) {
   atomicOr(&ctl->error, code);
+  if (fault) *fault = 1.f;   // sits behind the gradients: all-reduced with them, makes Adam a no-op on every rank
   if (sticky) __hip_atomic_store(sticky, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible, never cleared by a launch
 }
 
-__device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, unsigned* info, unsigned& xcc, unsigned& member) {
+__device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, float* fault, unsigned* info, unsigned& xcc,
+                                           unsigned& member) {
   if (threadIdx.x == 0) {
     const unsigned x = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
     info[0] = x;
@@ -116,7 +119,7 @@ __device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, un
   xcc = info[0];
   member = info[1];
   if (xcc >= 8 || member >= 32) {
-    if (threadIdx.x == 0) raise_error(ctl, sticky, 2u);
+    if (threadIdx.x == 0) raise_error(ctl, sticky, fault, 2u);
     return false;
   }
   return true;
@@ -170,6 +173,8 @@ struct PersistGeom {
   int T, Bp, Hp, D;
   int ub;        // utterance rows per group and round (<= 4)
   int rounds;    // passes over the batch (weights stay in registers)
+  int inject;    // test hook (NASR_PERSIST_FAULT=s): member 0 of every group treats the poll of step s as timed out
+  float* fault;  // device word raised by an aborted launch (or NULL)
 };
 
 constexpr int PERSIST_LDS_BYTES = 96 * 1024;   // > half of the CU's 160 KB: one workgroup per CU
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
   unsigned* info = reinterpret_cast<unsigned*>(lds + LDS_INFO);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   unsigned xcc, member;
-  if (!join_group(ctl, sticky, info, xcc, member)) return;
+  if (!join_group(ctl, sticky, gm.fault, info, xcc, member)) return;
   const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D;
   const int NGD = 8 / D, d = (int)xcc / NGD, grp = (int)xcc % NGD;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
       bool ok = true;
       if (w < 4) {
         // 1. the 8 producers of this wave's K quarter have published h_{s-1} (and finished with h_{s-2})
-        ok = poll_ge(gflag + w * 8 + (lane & 7), lane < 8, tagbase + (unsigned)s);
+        ok = poll_ge(gflag + w * 8 + (lane & 7), lane < 8, tagbase + (unsigned)s) && !(s == gm.inject && member == 0);
         stp.mark(1);
         f32x4 acc[4];
 #pragma unroll
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
     if (w == 4) store_side(T - 1);
   }
   stp.flush(ctl);
-  if (aborted && tid == 0) raise_error(ctl, sticky, 1u);
+  if (aborted && tid == 0) raise_error(ctl, sticky, gm.fault, 1u);
 }
 
 // ------------------------------------------------------------------ BPTT
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
   unsigned* info = reinterpret_cast<unsigned*>(lds + LDS_INFO);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   unsigned xcc, member;
-  if (!join_group(ctl, sticky, info, xcc, member)) return;
+  if (!join_group(ctl, sticky, gm.fault, info, xcc, member)) return;
   const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D;
   const int NGD = 8 / D, d = (int)xcc / NGD, grp = (int)xcc % NGD;
   const int N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
             const unsigned v1 = __hip_atomic_load(gflag + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = __all((int)(v0 - want) >= 0 && (int)(v1 - want) >= 0);
           }
+          if (k == gm.inject && member == 0) ok = false;
         }
         stp.mark(1);
         const bool valid = rowok && s < len;
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
     __syncthreads();                  // pfb / adg are reused by the next round
   }
   stp.flush(ctl);
-  if (aborted && tid == 0) raise_error(ctl, sticky, 1u);
+  if (aborted && tid == 0) raise_error(ctl, sticky, gm.fault, 1u);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -590,6 +596,9 @@ static PersistGeom make_geom(const LstmDims& dm) {
   g.ub = (dm.Bp + NGD - 1) / NGD;
   if (g.ub > 4) g.ub = 4;
   g.rounds = (dm.Bp + NGD * g.ub - 1) / (NGD * g.ub);
+  const char* e = getenv("NASR_PERSIST_FAULT");
+  g.inject = (e && *e) ? atoi(e) : -1;
+  g.fault = nullptr;
   return g;
 }
 
@@ -613,9 +622,10 @@ hipError_t persist_prepare() {
 }
 
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates, float* cbuf, float* out,
-                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float forget_bias,
-                             hipStream_t st) {
-  const PersistGeom gm = make_geom(dm);
+                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
+                             float forget_bias, hipStream_t st) {
+  PersistGeom gm = make_geom(dm);
+  gm.fault = fault;
   (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(320);
 #define NASR_PF(NUV)                                                                                                  \
@@ -632,8 +642,9 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates,
 
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
-                             hipStream_t st) {
-  const PersistGeom gm = make_geom(dm);
+                             float* fault, hipStream_t st) {
+  PersistGeom gm = make_geom(dm);
+  gm.fault = fault;
   (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(320);
 #define NASR_PB(NUV)                                                                                                   \

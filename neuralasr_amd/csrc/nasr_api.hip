@@ -57,6 +57,7 @@ struct TensorInfo {
 enum Phase { PH_PACK = 0, PH_XPROJ, PH_RECF, PH_PROJCTC, PH_PROJB, PH_RECB, PH_WGRAD, PH_ADAM, PH_COUNT };
 
 constexpr int PIPE_MAX_CHUNKS = 16;
+constexpr int GRAD_TAIL = 32;   // floats behind the gradients; [0] = fault word of the step
 
 struct GraphKey {
   int T, l, bwd, s0;
@@ -94,6 +95,7 @@ struct nasr_ctx {
   bool persist = false;
   bool persist_ok = false;             // the device passed the census at create time
   bool persist_used = false;           // a persistent launch is in flight since the last check of *perr
+  int adam_unverified = 0;             // Adam launches since the last check of the step's fault word
   float *Upf = nullptr, *Upb = nullptr;   // [L][D] operand images
   size_t imf = 0, imb = 0;             // floats per (layer, direction) image
   float* xch = nullptr;                // exchange buffer
@@ -616,10 +618,11 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
     const size_t k = (size_t)l * h->D;
     if (!bwd)
       launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->gates[l].as<float>(), h->cbuf[l].as<float>(),
-                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->cfg.forget_bias, st);
+                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->G + h->np_int,
+                              h->cfg.forget_bias, st);
     else
       launch_lstm_persist_bwd(dm, h->Upb + k * h->imb, h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(),
-                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl, h->perr, st);
+                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->G + h->np_int, st);
     h->persist_used = true;
     HIPCHK(h, hipGetLastError());
     return NASR_OK;
@@ -1221,14 +1224,15 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       return bail(NASR_ERR_HIP, "hipMalloc of transposed weights failed");
   }
   const size_t nb = (size_t)h->np_int * 4;
+  const size_t gb = nb + GRAD_TAIL * 4;   // the gradient buffer ends with the fault word (+ padding): see nasr_grad_device_count
   const size_t ub = (size_t)h->L * h->D * h->Hp * h->N4 * 4;
   if (hipMalloc(&h->P, nb) != hipSuccess || hipMalloc(&h->M, nb) != hipSuccess || hipMalloc(&h->V, nb) != hipSuccess ||
-      hipMalloc(&h->G, nb) != hipSuccess || hipMalloc(&h->Uf, ub) != hipSuccess || hipMalloc(&h->Ub, ub) != hipSuccess)
+      hipMalloc(&h->G, gb) != hipSuccess || hipMalloc(&h->Uf, ub) != hipSuccess || hipMalloc(&h->Ub, ub) != hipSuccess)
     return bail(NASR_ERR_HIP, "hipMalloc of parameter buffers failed");
   (void)hipMemsetAsync(h->P, 0, nb, h->st);
   (void)hipMemsetAsync(h->M, 0, nb, h->st);
   (void)hipMemsetAsync(h->V, 0, nb, h->st);
-  (void)hipMemsetAsync(h->G, 0, nb, h->st);
+  (void)hipMemsetAsync(h->G, 0, gb, h->st);
   (void)hipMemsetAsync(h->Uf, 0, ub, h->st);
   (void)hipMemsetAsync(h->Ub, 0, ub, h->st);
   {
@@ -1296,9 +1300,9 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       (void)hipMemcpyAsync(sq.p, two.data(), Bp * 4, hipMemcpyHostToDevice, h->st);
       const LstmDims dm{T, Bp, Bp, h->H, h->Hp, h->D};
       launch_lstm_persist_fwd(dm, h->Upf, g.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(), h->xch, h->pctl,
-                              h->perr, 1.f, h->st);
+                              h->perr, nullptr, 1.f, h->st);
       launch_lstm_persist_bwd(dm, h->Upb, g.as<float>(), dg.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(),
-                              h->xch, h->pctl, h->perr, h->st);
+                              h->xch, h->pctl, h->perr, nullptr, h->st);
       ok = hipStreamSynchronize(h->st) == hipSuccess && hipGetLastError() == hipSuccess && *h->perr == 0;
     }
     for (DevBuf* b : {&g, &c, &o, &dg, &sq}) b->release();
@@ -1457,6 +1461,7 @@ int nasr_compute_grads(nasr_handle h) {
     h->window_open = true;
     h->total_valid = false;
   }
+  HIPCHK(h, hipMemsetAsync(h->G + h->np_int, 0, GRAD_TAIL * 4, h->st));   // the step's fault word
   int rc = forward(h);
   if (rc) return rc;
   rc = ctc_forward(h);
@@ -1465,7 +1470,7 @@ int nasr_compute_grads(nasr_handle h) {
 }
 
 void* nasr_grad_device_ptr(nasr_handle h) { return h ? h->G : nullptr; }
-int64_t nasr_grad_device_count(nasr_handle h) { return h ? h->np_int : -1; }
+int64_t nasr_grad_device_count(nasr_handle h) { return h ? h->np_int + GRAD_TAIL : -1; }
 
 int nasr_apply_adam(nasr_handle h, float grad_scale) {
   if (!h) return NASR_ERR_ARG;
@@ -1474,11 +1479,12 @@ int nasr_apply_adam(nasr_handle h, float grad_scale) {
   {
     PhaseScope ps(h, PH_ADAM);
     h->adam_step += 1;
+    h->adam_unverified += 1;
     const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
     const double lr_t = (double)h->lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_step)) /
                         (1.0 - std::pow(b1, (double)h->adam_step));
     launch_adam(h->P, h->M, h->V, h->G, h->np_int, (float)lr_t, h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, grad_scale,
-                h->st);
+                h->G + h->np_int, h->st);
     int rc = repack(h);
     if (rc) return rc;
   }
@@ -1505,6 +1511,7 @@ int nasr_set_grads(nasr_handle h, const float* flat, int64_t n) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = scatter_to_device(h, flat, h->G);
   if (rc) return rc;
+  HIPCHK(h, hipMemsetAsync(h->G + h->np_int, 0, GRAD_TAIL * 4, h->st));
   h->have_grads = true;
   return NASR_OK;
 }
@@ -1542,8 +1549,21 @@ int nasr_label_error_rate(const int32_t* hyp_ids, const int32_t* hyp_lens, int h
 
 int nasr_get_loss(nasr_handle h, float* loss_out) {
   if (!h || !loss_out) return NASR_ERR_ARG;
+  // the step's fault word travels with the gradients through the all-reduce: non-zero = some rank's persistent
+  // recurrence gave up, every rank's Adam launch of that step was a no-op (optim.hip) and the step is void everywhere
+  float fault = 0.f;
   HIPCHK(h, hipMemcpyAsync(loss_out, h->loss.p, 4, hipMemcpyDeviceToHost, h->st));
-  return sync_checked(h);
+  HIPCHK(h, hipMemcpyAsync(&fault, h->G + h->np_int, 4, hipMemcpyDeviceToHost, h->st));
+  const int rc = sync_checked(h);
+  if (fault != 0.f) {
+    h->adam_step -= std::min<int64_t>(h->adam_unverified, h->adam_step);
+    h->adam_unverified = 0;
+    if (rc) return rc;
+    return h->fail(NASR_ERR_HIP, "this training step is void: the persistent recurrence of another rank aborted; no "
+                                 "parameters were changed on any rank");
+  }
+  h->adam_unverified = 0;
+  return rc;
 }
 
 int nasr_resident_frames(nasr_handle h, int64_t* frames) {

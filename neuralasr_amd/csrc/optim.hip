@@ -12,7 +12,10 @@ namespace nasr {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, int64_t n4, float lr_t, float b1,
-                                                   float b2, float eps, float gscale) {
+                                                   float b2, float eps, float gscale, const float* __restrict__ fault) {
+  // A persistent-recurrence launch that gave up marks the gradient buffer's fault word (it is all-reduced with the
+  // gradients, so every rank sees it): such a step must not touch the parameters, on any rank.
+  if (fault && *fault != 0.f) return;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 gg = reinterpret_cast<const float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i];
@@ -34,11 +37,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 }
 
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr_t, float beta1, float beta2,
-                 float eps, float gscale, hipStream_t st) {
+                 float eps, float gscale, const float* fault, hipStream_t st) {
   const int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, m, v, g, n4, lr_t, beta1, beta2, eps, gscale);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, m, v, g, n4, lr_t, beta1, beta2, eps, gscale, fault);
 }
 
 // ---- column sums: stage 1 writes part[rs][n] for 32 row slices, stage 2 adds them in order

@@ -137,3 +137,35 @@ def test_wide_layer_uses_the_two_launch_bptt_step():
         g = grads[off:off + r * c].reshape(g_o.shape)
         assert np.linalg.norm(g - g_o) <= 1e-4 * np.linalg.norm(g_o) + 1e-6 * scale, name
     e.close()
+
+
+def test_aborted_persistent_launch_voids_the_step_and_falls_back(monkeypatch):
+    """Fault injection (NASR_PERSIST_FAULT=s: one workgroup per group treats the hand-off of step s as timed out).
+    The launch drains through its bounded spins, raises the sticky error word and the gradient buffer's fault word;
+    Adam of that step is a no-op (parameters and Adam state untouched), the error surfaces at the next host sync, and
+    the handle continues on the per-step kernels with correct results."""
+    from neuralasr_amd import _lib
+    spec = O.ModelSpec(12, 60, 2, True, 'concat', 7)
+    B, T = 6, 16
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=5, var_len=True, Lmin=1, Lmax=3)
+    params = rand_params(spec, 8)
+    start = O.flatten(params).astype(np.float32)
+    e = make_engine(spec, lr=1e-2)
+    e.set_params(start)
+    assert e.recurrence_mode == 'persistent'
+    monkeypatch.setenv('NASR_PERSIST_FAULT', '3')
+    with pytest.raises(_lib.NasrError, match='persistent recurrence aborted'):
+        e.train_step(feats, seq_len, labels, label_len)
+    monkeypatch.delenv('NASR_PERSIST_FAULT')
+    assert e.recurrence_mode == 'per-step'
+    np.testing.assert_array_equal(e.get_params(), start)              # the void step changed nothing
+    m, v, step = e.get_adam_state()
+    assert step == 0 and not m.any() and not v.any()
+    with pytest.raises(_lib.NasrError):
+        e.set_recurrence_mode(True)                                   # not offered again on this handle
+    loss = e.train_step(feats, seq_len, labels, label_len)            # the same step on the per-step kernels
+    loss_o, _, _, _ = O.network_loss_and_grads(spec, [p.astype(np.float32).astype(np.float64) for p in params], feats,
+                                               seq_len, labels, label_len)
+    assert loss == pytest.approx(loss_o, rel=2e-5)
+    assert e.get_adam_state()[2] == 1 and np.abs(e.get_params() - start).max() > 1e-4
+    e.close()

@@ -94,7 +94,7 @@ int main(int argc, char** argv) {
     // ---- forward, persistent
     CK(hipMemcpyAsync(gatesB, gates0, R * D * N4 * 4, hipMemcpyDeviceToDevice, st));
     CK(hipEventRecord(e0, st));
-    launch_lstm_persist_fwd(dm, Upf, gatesB, cB, outB, seq, xch, ctl, nullptr, 1.0f, st);
+    launch_lstm_persist_fwd(dm, Upf, gatesB, cB, outB, seq, xch, ctl, nullptr, nullptr, 1.0f, st);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGetLastError());
     CK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     const float bstep = ms;
     CK(hipEventRecord(e0, st));
-    launch_lstm_persist_bwd(dm, Upb, gatesB, dgB, cB, dout, seq, xch, ctl, nullptr, st);
+    launch_lstm_persist_bwd(dm, Upb, gatesB, dgB, cB, dout, seq, xch, ctl, nullptr, nullptr, st);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGetLastError());
     CK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
