@@ -132,7 +132,10 @@ int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len
  *   nasr_upload_batch(shard) ; nasr_compute_grads ; all-reduce(sum) nasr_grad_device_ptr over
  *   RCCL ; nasr_apply_adam(1/world) ; nasr_get_loss
  * The gradient buffer is one flat fp32 device array of nasr_grad_device_count elements in the
- * library's padded internal layout (identical on every rank; padding elements are always 0). */
+ * library's padded internal layout (identical on every rank; padding elements are always 0).  Its last 32
+ * floats are not gradients: the first of them is the step's FAULT word (0, or 1 when this rank's persistent
+ * recurrence gave up).  Reduce the whole array: a non-zero sum makes nasr_apply_adam a no-op on every rank and
+ * nasr_get_loss return NASR_ERR_HIP ("step void"), so the replicas never diverge. */
 int nasr_upload_batch(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
                       const int32_t* label_len, int B, int T, int Lmax);
 /* Same, but the context stacking of utils.py:8-21 (include_context) happens on the device: `centre` is the
