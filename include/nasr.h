@@ -155,6 +155,10 @@ int nasr_apply_adam(nasr_handle h, float grad_scale); /* g*grad_scale, TF Adam, 
 int nasr_get_grads(nasr_handle h, float* flat, int64_t n);
 int nasr_set_grads(nasr_handle h, const float* flat, int64_t n);
 int nasr_get_loss(nasr_handle h, float* loss_out);    /* synchronises; loss of last compute_grads */
+/* synchronises; *void_out = 1 when the (all-reduced) fault word of the last step is set: nasr_apply_adam was a no-op on
+ * every rank and the caller should run the step again (a rank whose persistent recurrence aborted has switched to the
+ * per-step kernels by then).  Call it after nasr_apply_adam on every rank: all ranks get the same answer. */
+int nasr_step_void(nasr_handle h, int* void_out);
 int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the resident batch */
 
 /* TensorFlowNetwork.train fetches mean_ler with every step (networks/tfnetwork.py:188-189): with

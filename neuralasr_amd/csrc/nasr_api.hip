@@ -1566,6 +1566,18 @@ int nasr_get_loss(nasr_handle h, float* loss_out) {
   return rc;
 }
 
+int nasr_step_void(nasr_handle h, int* void_out) {
+  if (!h || !void_out) return NASR_ERR_ARG;
+  float fault = 0.f;
+  HIPCHK(h, hipMemcpyAsync(&fault, h->G + h->np_int, 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  (void)persist_check(h);   // a local abort: switch this handle to the per-step kernels (the message stays in last_error)
+  *void_out = fault != 0.f ? 1 : 0;
+  if (fault != 0.f) h->adam_step -= std::min<int64_t>(h->adam_unverified, h->adam_step);
+  h->adam_unverified = 0;
+  return NASR_OK;
+}
+
 int nasr_resident_frames(nasr_handle h, int64_t* frames) {
   if (!h || !frames) return NASR_ERR_ARG;
   *frames = h->resident ? h->frames : 0;

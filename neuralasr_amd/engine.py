@@ -258,6 +258,14 @@ class Engine:
         self._ck(self.lib.nasr_get_loss(self.h, byref(loss)))
         return float(loss.value)
 
+    def step_void(self):
+        """True when the step just applied was void on every rank (some rank's persistent recurrence aborted; Adam was
+        a no-op everywhere): run it again.  Synchronises."""
+        from ctypes import c_int
+        v = c_int()
+        self._ck(self.lib.nasr_step_void(self.h, byref(v)))
+        return bool(v.value)
+
     def resident_frames(self):
         n = c_int64()
         self._ck(self.lib.nasr_resident_frames(self.h, byref(n)))

@@ -163,6 +163,18 @@ class HipNetwork(Network):
 
     def train(self, mfccs, labels, seq_len, labels_len):
         self.global_step += 1
+        for attempt in range(3):
+            out = self._train_once(mfccs, labels, seq_len, labels_len)
+            # a rank whose persistent recurrence gave up voids the step on EVERY rank (the fault word is all-reduced with
+            # the gradients and turns Adam into a no-op); that rank now runs the per-step kernels: do the step again
+            if out is not None and not self.engine.step_void():
+                return out
+            self.logger.warning('step %d was void (persistent recurrence aborted on some rank): repeating it'
+                                % self.global_step)
+        raise RuntimeError('training step %d stayed void after 3 attempts' % self.global_step)
+
+    def _train_once(self, mfccs, labels, seq_len, labels_len):
+        from .._lib import NasrError
         n, mine = self._towers()
         losses, lers, gsum = [], [], None
         for k in mine:
@@ -172,7 +184,14 @@ class HipNetwork(Network):
                     self.engine.upload_batch_context(f, s, l, ll, ctx, self.config.numcep)):
                 self.engine.upload_batch(f, s, l, ll)
             self.engine.compute_grads()
-            losses.append(self.engine.get_loss())
+            try:
+                losses.append(self.engine.get_loss())
+            except NasrError as exc:            # keep the collective protocol going; the step is repeated by train()
+                if 'persistent recurrence aborted' not in str(exc):
+                    raise
+                if self.coll.world == 1:
+                    return None                 # single process: nothing else to keep in step, just repeat
+                losses.append(float('nan'))
             hyps = (self._decode(f, s, 'beam') if self.train_ler_decoder == 'beam'
                     else self.engine.get_decoded(len(s), f.shape[1]))
             lers.append(self.engine.label_error_rate(hyps, l, ll))

@@ -220,3 +220,25 @@ def test_deepspeech_plugin_trains_and_validates(tmp_path, monkeypatch):
     assert glob.glob(os.path.join(cfg.model_dir, 'model-8.npz'))
     ids = net.decode(mfccs[:1], seq_len[:1])
     assert ids.ndim == 1
+
+
+def test_train_repeats_a_void_step(tmp_path, monkeypatch, caplog):
+    """HipNetwork.train with a fault injected into the persistent recurrence (NASR_PERSIST_FAULT): the step is void,
+    train() repeats it on the per-step kernels and returns what an undisturbed step returns."""
+    import logging
+    cfg = Config(make_config(tmp_path, num_gpus='1'), True)
+    net = cfg.load_network(fortraining=True)
+    ref = Config(make_config(tmp_path, num_gpus='1', model_dir=str(tmp_path / 'model2')), True).load_network(fortraining=True)
+    ref.engine.set_params(net.engine.get_params())
+    assert net.engine.recurrence_mode == 'persistent'
+    ds = DataSet(cfg.train_input, cfg)
+    mfccs, labels, seq_len, labels_len = ds.get_next_batch()
+    want = ref.train(mfccs, labels, seq_len, labels_len)
+    monkeypatch.setenv('NASR_PERSIST_FAULT', '2')
+    with caplog.at_level(logging.WARNING):
+        got = net.train(mfccs, labels, seq_len, labels_len)
+    monkeypatch.delenv('NASR_PERSIST_FAULT')
+    assert net.engine.recurrence_mode == 'per-step' and net.global_step == 1
+    assert float(got[0]) == pytest.approx(float(want[0]), rel=2e-6) and float(got[1]) == pytest.approx(float(want[1]), abs=1e-6)
+    np.testing.assert_allclose(net.engine.get_params(), ref.engine.get_params(), rtol=0, atol=5e-5)
+    assert net.engine.get_adam_state()[2] == 1
