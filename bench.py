@@ -214,6 +214,25 @@ def main():
         step()
     fence()
     dt_h2d = (time.perf_counter() - t1) / NH
+    # ---- and fed the way HipNetwork.train feeds it: features with the include_context structure of preprocess_mfcc.py
+    # (utils.py:8-21) go over PCIe as their centre [B,T,numcep] slice and are re-stacked on the device
+    dt_ctx = None
+    if spec.feature_size == 21 * 26:
+        from neuralasr_amd.utils import include_context
+        rs = np.random.RandomState(77 + rank)
+        fctx = np.zeros((B, T, spec.feature_size), np.float32)
+        for b in range(B):
+            fctx[b, :seq_len[b]] = include_context(rs.randn(int(seq_len[b]), 26).astype(np.float32), 10, 26)
+        if eng.upload_batch_context(fctx, seq_len, labels, label_len, 10, 26):
+            step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(NH):
+                eng.upload_batch_context(fctx, seq_len, labels, label_len, 10, 26)
+                step()
+            fence()
+            dt_ctx = (time.perf_counter() - t1) / NH
+            eng.upload_batch(feats, seq_len, labels, label_len)      # back to the bench batch for the phase timings
     # ---- the gradient all-reduce alone (time per step and bus bandwidth), N > 1 only
     ar_ms = None
     if use_dist and world > 1:
@@ -285,6 +304,11 @@ def main():
             'incl_h2d': {'ms_per_step': dt_h2d * 1e3, 'value': float(frames) * world / dt_h2d, 'unit': 'frames/s',
                          'note': 'features uploaded from host memory every step (PCIe-inclusive); rank-0 clock'},
         }
+        if dt_ctx is not None:
+            out['incl_h2d']['context_upload'] = {
+                'ms_per_step': dt_ctx * 1e3, 'value': float(frames) * world / dt_ctx,
+                'note': 'context-stacked features uploaded as their centre slice, stacking rebuilt on the device '
+                        '(nasr_upload_batch_context, what HipNetwork.train does)'}
         if ar_ms is not None:
             gbytes = gt.numel() * 4 / 1e9
             out['allreduce'] = {'ms': ar_ms, 'bytes': gt.numel() * 4,
