@@ -18,9 +18,10 @@
 //   * the 4 utterances are the 4 rows of v_mfma_f32_4x4x1_16b_f32 (exact fp32): its 16 blocks are 16 hidden
 //     units x (i,j,f,o), the A operand (h) is broadcast from one block with cbsz/abid, so one 16-byte load per
 //     lane feeds 64 MFMAs.
-//   * forward step: each wave waits for the 8 producers of its K quarter (one flag word each), loads their h
+//   * forward step: each MFMA wave waits for the 8 producers of its K quarter (one flag word each), loads their h
 //     (2 x 16 B per lane), 128 MFMAs, 4-wave LDS reduction, wave 0 does the 64 cell updates (c stays in a
-//     register for the whole sequence), publishes h and the flag.
+//     register for the whole sequence), publishes h and the flag.  A fifth wave owns the per-frame HBM traffic
+//     (gates in, activations / c / out out) and talks to the cell wave through LDS.
 //   * BPTT step: split-K the other way round (as lstm.hip): a CU turns dh of its own 16 units into dG (dc stays
 //     in a register), multiplies by ITS columns of U for all Hp outputs and hands 32 partial rows to the 32
 //     consumers; the consumer sums 32 partials.  Deterministic, no atomics.
@@ -36,9 +37,6 @@
 #include <type_traits>
 #include <utility>
 
-#ifndef NASR_PABL
-#define NASR_PABL 0     // timing experiments only (results wrong): 1 = forward without its side stores and prefetch
-#endif
 #ifndef NASR_PSTAMP
 #define NASR_PSTAMP 0   // 1: wave 0 of one workgroup accumulates s_memtime deltas per phase into PersistCtl::pad (tools/persistbench)
 #endif
