@@ -32,7 +32,11 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int TPB = 1024;                       // bytes of one tile
 constexpr int BUF_BYTES = 48 * TPB;             // A: 8 row blocks x 3 parts, B: 8 x 3
-constexpr int GEMM_TP_LDS = 2 * BUF_BYTES;
+#ifndef NASR_TP_NBUF
+#define NASR_TP_NBUF 2      // LDS buffers: 2 = one k-step of DMA in flight; 3 = two (counted vmcnt + raw s_barrier):
+                            // measured 0-1 % SLOWER on every shape of tools/gemmbench.hip - DMA latency is not the limit
+#endif
+constexpr int GEMM_TP_LDS = NASR_TP_NBUF * BUF_BYTES;
 
 __device__ __attribute__((aligned(1024))) unsigned char g_tp_zero[TPB];   // what out-of-range tiles read
 
@@ -154,12 +158,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int foff = tp_slot(lane & 31, lane >> 5);
+#if NASR_TP_NBUF == 2
   if (kb0 < kb1) issue(kb0, 0);
   for (int kb = kb0; kb < kb1; ++kb) {
     const int buf = (kb - kb0) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's tiles of step kb have landed ...
     __syncthreads();                                    // ... and everybody's; buffer buf^1 is no longer being read
     if (kb + 1 < kb1) issue(kb + 1, buf ^ 1);
+#else
+  // experiment (see NASR_TP_NBUF): three buffers, two k-steps of DMA in flight.  Counted vmcnt (6 DMAs per wave and
+  // step) and a raw s_barrier: a __syncthreads() would drain the DMA queue (vmcnt(0)).
+  if (kb0 < kb1) issue(kb0, 0);
+  if (kb0 + 1 < kb1) issue(kb0 + 1, 1);
+  int buf = 0;
+  for (int kb = kb0; kb < kb1; ++kb) {
+    if (kb + 1 < kb1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the newest step's tiles have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // everybody's; the buffer read in step kb-1 is free again
+    asm volatile("" ::: "memory");
+    if (kb + 2 < kb1) issue(kb + 2, buf >= 1 ? buf - 1 : 2);
+#endif
     const unsigned char* ab = lds + buf * BUF_BYTES + foff;
     bf16x8 a[4][3], b[2][3];
 #pragma unroll
@@ -183,6 +201,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
         acc[i][j] = c;
       }
+#if NASR_TP_NBUF != 2
+    buf = buf == 2 ? 0 : buf + 1;
+#endif
   }
 
   // epilogue: C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
