@@ -284,12 +284,16 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
         if (s > 0 && ok) {
           // 2. h_{s-1} of this K quarter: chunk = (unit/4)*4 + utterance, 16 B = 4 consecutive units
           const float* src = ghx + (size_t)((s - 1) & 1) * Hp * 4 + ((size_t)w * KW * 4 + (size_t)lane * 4);
-          if constexpr (NJ == 2) {
+          if constexpr (NCH == 32) {
             asm volatile(
                 "global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
                 : "=&v"(P[0]), "=&v"(P[1])
                 : "v"(src)
                 : "memory");
+          } else if constexpr (NJ == 2) {   // the second load covers chunks 16 .. NCH-1 only
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(P[0]) : "v"(src) : "memory");
+            if (lane < 4 * (NCH - 16)) asm volatile("global_load_dwordx4 %0, %1, off offset:1024 sc1" : "=&v"(P[1]) : "v"(src) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(P[0]), "+v"(P[1]) : : "memory");
           } else {
             if (lane < 4 * NCH)
               asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(P[0]) : "v"(src) : "memory");
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
 // ------------------------------------------------------------------ launchers
 bool persist_supported(int Hp) {
   const int NU = Hp / 32;
-  return Hp % 32 == 0 && (NU == 2 || NU == 4 || NU == 8 || NU == 16);
+  return Hp % 64 == 0 && NU >= 2 && NU <= 16;   // every padded hidden size up to 512
 }
 
 static PersistGeom make_geom(const LstmDims& dm) {
@@ -614,7 +618,7 @@ hipError_t persist_prepare() {
   if (e == hipSuccess)                                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_bwd_kernel<NUV>),                           \
                             hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS_BYTES);
-  NASR_PATTR(2) NASR_PATTR(4) NASR_PATTR(8) NASR_PATTR(16)
+  NASR_PATTR(2) NASR_PATTR(4) NASR_PATTR(6) NASR_PATTR(8) NASR_PATTR(10) NASR_PATTR(12) NASR_PATTR(14) NASR_PATTR(16)
 #undef NASR_PATTR
   return e;
 }
@@ -632,7 +636,11 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates,
   switch (dm.Hp / 32) {
     case 2: NASR_PF(2); break;
     case 4: NASR_PF(4); break;
+    case 6: NASR_PF(6); break;
     case 8: NASR_PF(8); break;
+    case 10: NASR_PF(10); break;
+    case 12: NASR_PF(12); break;
+    case 14: NASR_PF(14); break;
     default: NASR_PF(16); break;
   }
 #undef NASR_PF
@@ -651,7 +659,11 @@ void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* 
   switch (dm.Hp / 32) {
     case 2: NASR_PB(2); break;
     case 4: NASR_PB(4); break;
+    case 6: NASR_PB(6); break;
     case 8: NASR_PB(8); break;
+    case 10: NASR_PB(10); break;
+    case 12: NASR_PB(12); break;
+    case 14: NASR_PB(14); break;
     default: NASR_PB(16); break;
   }
 #undef NASR_PB

@@ -91,7 +91,7 @@ struct nasr_ctx {
   unsigned char* WbTP = nullptr;       // per layer (l >= 1) TP of Wx [Ip][D*N4]: B operand of the input-gradient GEMM
   std::vector<size_t> off_wftp, off_wbtp;
   // Persistent recurrence (lstm_persist.hip): one launch per layer pass instead of T step launches.  Needs the full
-  // 8 XCD x 32 CU chip and Hp in {64,128,256,512}; NASR_PERSIST=0 keeps the per-step kernels.
+  // 8 XCD x 32 CU chip and Hp <= 512; NASR_PERSIST=0 keeps the per-step kernels.
   bool persist = false;
   bool persist_ok = false;             // the device passed the census at create time
   bool persist_used = false;           // a persistent launch is in flight since the last check of *perr

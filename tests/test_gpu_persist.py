@@ -1,7 +1,7 @@
 """GPU: the persistent recurrence (neuralasr_amd/csrc/lstm_persist.hip: one launch per layer pass, one XCD per
 (direction, utterance slice)) against the fp64 oracle AND against the per-timestep kernels of lstm.hip on the same
 inputs, through the C ABI.  Same tolerances as tests/test_gpu_parity.py.  The shapes exercise every
-kernel instantiation (Hp 64 / 128 / 256 / 512), several rounds over the batch (B > 16 bidirectional), partly filled
+kernel instantiation family (Hp 64 / 128 / 192 / 256 / 320 / 512), several rounds over the batch (B > 16 bidirectional), partly filled
 utterance slices, ragged lengths with T far above the shortest utterance, and the per-step fallback for hidden sizes the
 persistent kernels do not cover."""
 import numpy as np
@@ -31,6 +31,8 @@ CASES = [
     (O.ModelSpec(26, 500, 1, True, 'stack_reshape', 29), 16, 48),  # 512  the literal BiLstmCTCNet width
     (O.ModelSpec(12, 460, 1, False, 'none', 7), 40, 18),          # 512 (padded from 460) uni, Bp 48: 2 rounds of 8 x 4
     (O.ModelSpec(12, 120, 3, False, 'none', 9), 3, 90),           # 128  3-layer uni stack, B 3
+    (O.ModelSpec(15, 300, 1, True, 'concat', 8), 7, 22),          # 320  NU 10: partly filled second h load / output group
+    (O.ModelSpec(11, 180, 2, False, 'none', 6), 10, 26),          # 192  NU 6
 ]
 
 
@@ -102,7 +104,7 @@ def test_training_steps_agree_between_modes():
 
 
 def test_unsupported_width_uses_per_step_kernels():
-    """Hp = 704 (22 units per CU) has no persistent instantiation: the engine reports and uses the per-step kernels,
+    """Hp = 704 > 512 (22 units per CU: the slice of U no longer fits the registers) has no persistent instantiation: the engine reports and uses the per-step kernels,
     and asking for the persistent ones is an error, not a silent fallback."""
     spec = O.ModelSpec(10, 700, 1, True, 'concat', 5)
     B, T = 2, 9
