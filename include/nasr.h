@@ -195,7 +195,9 @@ int nasr_set_graph_mode(nasr_handle h, int enabled); /* capture the per-timestep
  * networks/lstm_ctc_net.py:22-23) runs: 1 = one persistent launch per layer pass (one XCD per direction and
  * utterance slice, recurrent matrix resident in registers), 0 = one launch per timestep.  nasr_set_recurrence_mode(0)
  * forces the per-step kernels; (1) asks for the persistent ones again and returns NASR_ERR_STATE where the device or
- * the hidden size does not support them. */
+ * the hidden size does not support them.  A persistent launch wants every CU of the device for itself: if another
+ * process or handle keeps CUs busy for longer than its bounded spins (~0.5 s), the launch gives up, the step is void
+ * (nasr_step_void) and this handle continues on the per-step kernels. */
 int nasr_get_recurrence_mode(nasr_handle h);
 int nasr_set_recurrence_mode(nasr_handle h, int persistent);
 
