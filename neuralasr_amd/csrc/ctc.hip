@@ -13,6 +13,8 @@
 // prefetched four frames ahead; (3) gradient, one wave per (t,b) row, class posteriors binned in LDS.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace nasr {
 
 constexpr float NEG = -1e30f;
@@ -20,6 +22,27 @@ constexpr float NEG = -1e30f;
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(a, fmaxf(b, c));
   return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+// lane l <- lane l-1 / l+1 as ONE DPP move (wave_shr:1 / wave_shl:1; the first / last lane gets `edge`) instead of a
+// ds_bpermute round trip through the LDS crossbar: the two neighbour exchanges of a lattice step are on its dependent chain
+template <bool DPP>
+__device__ __forceinline__ float lane_up1(float v, float edge) {
+  if constexpr (DPP) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+  } else {
+    const float r = __shfl_up(v, 1);
+    return (threadIdx.x & 63) == 0 ? edge : r;
+  }
+}
+template <bool DPP>
+__device__ __forceinline__ float lane_down1(float v, float edge) {
+  if constexpr (DPP) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+  } else {
+    const float r = __shfl_down(v, 1);
+    return (threadIdx.x & 63) == 63 ? edge : r;
+  }
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -64,7 +87,7 @@ void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, 
 // ulp is 1.2e-4 and alpha+beta-logp (the posterior exponent) loses 3 digits; rescaled columns stay O(10).
 // The time loop runs in branch-free groups of 4 frames (loads clamped, updates selected) so the emission
 // gathers of the NEXT group are in flight behind counted waits while this group computes.
-template <int KS>
+template <int KS, bool DPP>
 __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     const float* __restrict__ logits, const float* __restrict__ logz, const int* __restrict__ labels,
     const int* __restrict__ label_len, const int* __restrict__ seq_len, float* __restrict__ alpha,
@@ -141,10 +164,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
       for (int k = 0; k < 4; ++k) {
         const int t = t0 + k;
         const bool live = t < Tb;
-        float p1 = __shfl_up(a[KS - 1], 1);
-        float p2 = (KS >= 2) ? __shfl_up(a[KS >= 2 ? KS - 2 : 0], 1) : __shfl_up(a[0], 2);
-        if (lane == 0) { p1 = NEG; p2 = NEG; }
-        if (KS == 1 && lane == 1) p2 = NEG;
+        float p1 = lane_up1<DPP>(a[KS - 1], NEG);
+        float p2 = (KS >= 2) ? lane_up1<DPP>(a[KS >= 2 ? KS - 2 : 0], NEG) : __shfl_up(a[0], 2);
+        if (KS == 1 && lane <= 1) p2 = NEG;
         float na[KS];
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
@@ -202,10 +224,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
         float bb[KS];
 #pragma unroll
         for (int i = 0; i < KS; ++i) bb[i] = act[i] ? bt[i] + e[k][i] : NEG;
-        float n1 = __shfl_down(bb[0], 1);
-        float n2 = (KS >= 2) ? __shfl_down(bb[KS >= 2 ? 1 : 0], 1) : __shfl_down(bb[0], 2);
-        if (lane == 63) { n1 = NEG; n2 = NEG; }
-        if (KS == 1 && lane == 62) n2 = NEG;
+        float n1 = lane_down1<DPP>(bb[0], NEG);
+        float n2 = (KS >= 2) ? lane_down1<DPP>(bb[KS >= 2 ? 1 : 0], NEG) : __shfl_down(bb[0], 2);
+        if (KS == 1 && lane >= 62) n2 = NEG;
         float nb[KS];
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
@@ -228,9 +249,14 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
 void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,
                            const int* label_len, const int* seq_len, float* alpha, float* beta, double* aoff,
                            double* boff, float* nll, double* logp, hipStream_t st) {
-#define NASR_AB(K)                                                                                              \
-  hipLaunchKernelGGL((ctc_alpha_beta_kernel<K>), dim3(d.B), dim3(128), 0, st, logits, logz, labels, label_len, \
-                     seq_len, alpha, beta, aoff, boff, nll, logp, d.Bp, d.Cp, d.C, d.Lmax, d.Tws)
+  static const bool no_dpp = getenv("NASR_CTC_DPP") && getenv("NASR_CTC_DPP")[0] == '0';
+#define NASR_AB(K)                                                                                                       \
+  if (no_dpp)                                                                                                            \
+    hipLaunchKernelGGL((ctc_alpha_beta_kernel<K, false>), dim3(d.B), dim3(128), 0, st, logits, logz, labels, label_len, \
+                       seq_len, alpha, beta, aoff, boff, nll, logp, d.Bp, d.Cp, d.C, d.Lmax, d.Tws);                    \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((ctc_alpha_beta_kernel<K, true>), dim3(d.B), dim3(128), 0, st, logits, logz, labels, label_len,  \
+                       seq_len, alpha, beta, aoff, boff, nll, logp, d.Bp, d.Cp, d.C, d.Lmax, d.Tws)
   switch (d.KS) {
     case 1: NASR_AB(1); break;
     case 2: NASR_AB(2); break;
