@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace nasr {
 
@@ -49,6 +50,21 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
+}
+// the same all-lanes maximum without the six ds_bpermute round trips (720 cycles on the lattice's dependent chain every
+// 4 frames): four DPP steps make every row of 16 lanes uniform, four v_readlane + scalar max join the rows
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+  const int vi = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -119,6 +135,23 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
 #pragma unroll
     for (int i = 0; i < KS; ++i) e[i] = act[i] ? v[i] - z : NEG;
   };
+  // The same in two halves, for the group-ahead prefetch: the loads are issued before a group of 4 frames and turned
+  // into emissions only after it.  (With `emit` hipcc computed v - z right behind the loads, i.e. waited for all 16
+  // gathers of the next group at the top of every group: ~500 of the ~900 cycles a frame took.)
+  auto emit_raw = [&](int t, float (&v)[KS], float& z) {
+    z = lz[(size_t)t * Bp];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) v[i] = lg[(size_t)t * rstride + ext[i]];
+  };
+  auto emit_finish = [&](float (&v)[KS], float z, float (&e)[KS]) {
+    asm volatile("" : "+v"(z));
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      float x = v[i];
+      asm volatile("" : "+v"(x));          // the load result enters hipcc's view here, not earlier
+      e[i] = act[i] ? x - z : NEG;
+    }
+  };
   float* ws = (w == 0 ? alpha : beta) + (size_t)b * Tws * KS * 64;
   double* off = (w == 0 ? aoff : boff) + (size_t)b * Tws;
   auto store = [&](int t, const float (&a)[KS], double o) {
@@ -130,7 +163,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     float m = a[0];
 #pragma unroll
     for (int i = 1; i < KS; ++i) m = fmaxf(m, a[i]);
-    m = wave_max(m);
+    m = DPP ? wave_max_dpp(m) : wave_max(m);
 #pragma unroll
     for (int i = 0; i < KS; ++i) a[i] = a[i] > 0.5f * NEG ? a[i] - m : NEG;
     o += (double)m;
@@ -156,9 +189,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) emit(min(1 + k, Tb - 1), e[k]);
     for (int t0 = 1; t0 < Tb; t0 += 4) {
-      float en[4][KS];
+      float vn[4][KS], zn[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) emit(min(t0 + 4 + k, Tb - 1), en[k]);
+      for (int k = 0; k < 4; ++k) emit_raw(min(t0 + 4 + k, Tb - 1), vn[k], zn[k]);
       renorm(a, A);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -178,10 +211,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
         for (int i = 0; i < KS; ++i) a[i] = live ? (act[i] ? na[i] : NEG) : a[i];
         store(t, a, A);              // rows Tb..Tb+2 of the workspace take dead copies (Tws = T+4)
       }
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < KS; ++i) e[k][i] = en[k][i];
+      for (int k = 0; k < 4; ++k) emit_finish(vn[k], zn[k], e[k]);
     }
 #pragma unroll
     for (int i = 0; i < KS; ++i) fin[lane * KS + i] = a[i];
@@ -213,9 +245,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) emit(max(Tb - 1 - k, 0), e[k]);
     for (int t0 = Tb - 2; t0 >= 0; t0 -= 4) {
-      float en[4][KS];
+      float vn[4][KS], zn[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) emit(max(t0 - 4 - k + 1, 0), en[k]);
+      for (int k = 0; k < 4; ++k) emit_raw(max(t0 - 4 - k + 1, 0), vn[k], zn[k]);
       renorm(bt, Bo);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -238,10 +270,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
         for (int i = 0; i < KS; ++i) bt[i] = live ? (act[i] ? nb[i] : NEG) : bt[i];
         if (live) store(t, bt, Bo);
       }
+      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < KS; ++i) e[k][i] = en[k][i];
+      for (int k = 0; k < 4; ++k) emit_finish(vn[k], zn[k], e[k]);
     }
   }
 }
