@@ -73,6 +73,8 @@ struct Stamps {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;
+typedef volatile __attribute__((address_space(3))) unsigned lds_vu32;   // a volatile access through a GENERIC pointer to LDS
+                                                                        // compiles to flat_store sc0 sc1 + vmcnt(0)
 
 __device__ __forceinline__ float psig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float ptanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
               asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(P[0]) : "v"(src) : "memory");
           }
         }
-        if (w == 0 && lane == 0) *reinterpret_cast<volatile unsigned*>(info + 4) = tagbase + (unsigned)s + 1u;   // MFMA phase starts
+        if (w == 0 && lane == 0) *(lds_vu32*)(info + 4) = tagbase + (unsigned)s + 1u;   // MFMA phase starts (ds_write)
         stp.mark(2);
         if (s > 0 && ok) {
           // 3. acc[.][utt] (16 units x 4 gates) += h[utt][k] * U[k][cols]; A broadcast from block bb%16
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
         // hand-off, 1.74; in an MFMA wave 1.64; in the cell wave 1.69.)
         *reinterpret_cast<f32x4*>(xgb + (par * 64 + lane) * 4) = xg_pf;
         const unsigned want = tagbase + (unsigned)s + 1u;
-        for (unsigned n = 0; n < (1u << 26) && (int)(*reinterpret_cast<volatile unsigned*>(info + 4) - want) < 0; ++n)
+        for (unsigned n = 0; n < (1u << 26) && (int)(*(lds_vu32*)(info + 4) - want) < 0; ++n)
           __builtin_amdgcn_s_sleep(1);
         if (s + 1 < T) xg_pf = load_xg(s + 1);     // the load first: its wait must not sit behind the stores' acknowledgements
         if (s > 0) store_side(s - 1);
