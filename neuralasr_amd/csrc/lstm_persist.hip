@@ -338,7 +338,9 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
 #if NASR_PSTAMP
       if (stp.on) for (int i = 1; i < 5; ++i) stp.acc[6 + i] += info[8 + i] - info[8];   // arrival of wave i after wave 0 (mod 2^32)
 #endif
-      if (info[2 + par]) { aborted = true; break; }
+      // (the abort word is tested at the END of the iteration: tested here, its LDS round trip sat in front of the cell
+      //  update's own reads on the cell wave's chain; an aborted step publishes garbage, which nobody uses)
+      const unsigned abort_word = info[2 + par];
       if (w == 0) {
         // 4. cell update: lane = (utterance q, unit u)
         const bool valid = rowok && s < len;
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
         stp.mark(6);
         if (lane == 0) *(ctl->flags + xcc * 128 + member) = tagbase + (unsigned)s + 1u;
       }
+      if (abort_word) { aborted = true; break; }
     }
     if (aborted) break;
     __syncthreads();                  // the last cell update's results are in LDS
@@ -543,11 +546,12 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
       }
       __syncthreads();
       stp.mark(4);
-      if (info[2 + par]) { aborted = true; break; }
+      const unsigned abort_word = info[2 + par];   // tested at the end of the iteration (see the forward kernel)
       if (w == 4) {
         // memory wave, while the others are in their MFMA phase: dG of this step out, operands of step k+2 in
         if (k + 2 < T) prefetch(T - 3 - k);    // loads first: their wait must not sit behind the store's acknowledgement
         store_dg(k);
+        if (abort_word) { aborted = true; break; }
         continue;
       }
       // 3. partial[utt][k'] = sum_c dG[utt][c] * U[k'][c] for this wave's output units, waves 0-3
@@ -579,6 +583,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stp.mark(6);
       if (lane == 0) *(ctl->flags + xcc * 128 + member * 4 + w) = tagbase + (unsigned)k + 1u;
+      if (abort_word) { aborted = true; break; }
     }
     if (aborted) break;
     __syncthreads();                  // pfb / adg are reused by the next round
