@@ -242,3 +242,30 @@ def test_train_repeats_a_void_step(tmp_path, monkeypatch, caplog):
     assert float(got[0]) == pytest.approx(float(want[0]), rel=2e-6) and float(got[1]) == pytest.approx(float(want[1]), abs=1e-6)
     np.testing.assert_allclose(net.engine.get_params(), ref.engine.get_params(), rtol=0, atol=5e-5)
     assert net.engine.get_adam_state()[2] == 1
+
+
+def test_overfits_a_fixed_batch_to_zero_label_error():
+    """End to end through the HIP path only: a small BiLSTM-CTC net trained on one fixed batch learns it by heart - the
+    loss falls by orders of magnitude and the greedy and beam decodes reproduce the labels exactly (persistent
+    recurrence, tiled-plane GEMMs, CTC, Adam, decoders all in the loop)."""
+    from neuralasr_amd.engine import Engine
+    spec = O.ModelSpec(20, 64, 1, True, 'concat', 12)
+    B, T = 6, 40
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=17, var_len=True, Lmin=3, Lmax=6)
+    e = Engine(spec.feature_size, spec.hidden, 1, True, 'concat', spec.num_classes, learning_rate=1e-2)
+    assert e.recurrence_mode == 'persistent'
+    e.set_params(O.flatten(O.init_params(spec, seed=4)).astype(np.float32))
+    first = e.train_step(feats, seq_len, labels, label_len)
+    for _ in range(400):
+        last = e.train_step(feats, seq_len, labels, label_len)
+    assert np.isfinite(last) and last < 0.02 * first
+    truth = [labels[b, :label_len[b]].tolist() for b in range(B)]
+    assert e.greedy_decode(feats, seq_len) == truth
+    logits = e.forward(feats, seq_len)
+    # ctc_beam_search_decoder's default merge_repeated=True also merges equal labels that a blank separated (SURVEY.md
+    # Appendix A.6): the reference's decoder cannot emit "6 6"
+    merged = [[v for i, v in enumerate(t) if i == 0 or v != t[i - 1]] for t in truth]
+    assert e.beam_search(logits, seq_len, 100, merge_repeated=True)[0] == merged
+    assert e.beam_search(logits, seq_len, 100, merge_repeated=False)[0] == truth
+    assert e.label_error_rate(truth, labels, label_len) == 0.0
+    e.close()
