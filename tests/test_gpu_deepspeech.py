@@ -8,7 +8,11 @@ import pytest
 
 from oracle import nasr_oracle as O
 
-pytestmark = pytest.mark.gpu
+import os
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('NASR_GEMM', 'tp') in ('bf16', 'f32'),
+                                 reason='the dense stages run on the tiled-plane GEMMs only (NASR_GEMM unset or tp)')]
 
 
 def make_engine(spec, lr=1e-3):

@@ -9,7 +9,11 @@ import pytest
 
 from oracle import nasr_oracle as O
 
-pytestmark = pytest.mark.gpu
+import os
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('NASR_PERSIST', '1')[:1] == '0',
+                                 reason='NASR_PERSIST=0 forces the per-step kernels: nothing persistent to test')]
 
 
 def make_engine(spec, lr=1e-3):
