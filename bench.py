@@ -110,6 +110,11 @@ def cpu_baseline(spec, B, seed):
         thr = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
     except Exception:
         thr = os.cpu_count() or 1
+    try:                                               # BLAS may size its pool by the host; the cgroup quota is what runs
+        from oracle.cref import usable_cpus
+        thr = min(thr, usable_cpus())
+    except Exception:
+        pass
     Tc = 24 if spec.deepspeech else (200 if spec.num_layers > 1 else 400)
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, Tc, seed=seed)
     params = O.init_params(spec, seed=1)
