@@ -33,8 +33,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 constexpr int TPB = 1024;                       // bytes of one tile
 constexpr int BUF_BYTES = 48 * TPB;             // A: 8 row blocks x 3 parts, B: 8 x 3
 #ifndef NASR_TP_NBUF
-#define NASR_TP_NBUF 2      // LDS buffers: 2 = one k-step of DMA in flight; 3 = two (counted vmcnt + raw s_barrier):
-                            // measured 0-1 % SLOWER on every shape of tools/gemmbench.hip - DMA latency is not the limit
+#define NASR_TP_NBUF 2      // LDS buffers: 2 = fragments read after the barrier of their own k-step; 3 = fragments of step k+1
+                            // read under the MFMAs of step k (DMA two steps ahead): measured equal or 1-4 % SLOWER on every
+                            // shape of tools/gemmbench.hip - neither DMA nor LDS-read latency is what limits this kernel
 #endif
 constexpr int GEMM_TP_LDS = NASR_TP_NBUF * BUF_BYTES;
 
@@ -114,50 +115,78 @@ void launch_tp_split(const float* src, unsigned char* tp, int rows, int K, int l
 }
 
 // ------------------------------------------------------------------ the GEMM
+// TMW = 32-row tiles per wave in M: 4 -> the 256 x 256 block tile, 3 -> 192 x 256 for M such as 576 = 3 x 192 (the
+// layer-0 weight gradient: with 256-row tiles a third of its blocks would work on 64 live rows)
+template <int TMW>
 __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  constexpr int TM = 64 * TMW;               // block rows
+  constexpr int NA3 = 3 * (TM / 32);         // A tiles per k-step (row blocks x parts)
+  constexpr int NT = NA3 + 24;               // + B tiles
+  constexpr int BUFB = NT * TPB;             // bytes of one LDS buffer
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.y * 256, n0 = blockIdx.x * 256;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 256;
   const int kb0 = blockIdx.z * p.kb_chunk;
   const int kb1 = min(p.kbs, kb0 + p.kb_chunk);
   const int wm = w >> 2, wn = w & 3;
 
-  // this wave's 6 of the 48 tiles of a k-step: tile ti = (operand, row block, part)
-  const unsigned char* tbase[6];   // address of the tile at k-block 0, or NULL when the row block is outside the matrix
-  int tstride[6], tshift[6], tnkb[6];
+  // this wave's 6 of the NT tiles of a k-step: tile ti = (operand, row block, part).  Everything here is wave-uniform
+  // (SGPRs); a tile outside its matrix, or a k-block outside the operand, reads the zero tile.
+  uint64_t zero = (uint64_t)g_tp_zero;
+  asm volatile("" : "+s"(zero));               // keep the address in SGPRs (otherwise re-fetched from the GOT per tile)
+  uint64_t tbase[6];                           // address of the tile at k-block 0, or 0 when the row block is outside the matrix
+  int tshift[6], tnkb[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const int ti = w * 6 + i;
-    const bool isB = ti >= 24;
-    const int t2 = isB ? ti - 24 : ti;
+    const int ti = min(w * 6 + i, NT - 1);      // (tiles past NT - 1 are never issued)
+    const bool isB = ti >= NA3;
+    const int t2 = isB ? ti - NA3 : ti;
     const int rbl = t2 / 3, part = t2 - 3 * rbl;
     const int rb = ((isB ? n0 : m0) >> 5) + rbl;
     const int nkb = isB ? p.nkbB : p.nkbA;
     const bool ok = rb * 32 < (isB ? p.N : p.M);
-    tbase[i] = ok ? (isB ? p.B : p.A) + ((size_t)rb * nkb * 3 + part) * TPB : nullptr;
-    tstride[i] = 3 * TPB;
+    tbase[i] = ok ? (uint64_t)(isB ? p.B : p.A) + ((size_t)rb * nkb * 3 + part) * TPB : 0;
     tshift[i] = isB ? 0 : p.a_kb_shift;
-    tnkb[i] = nkb;
+    tnkb[i] = ok ? nkb : 0;                     // 0: every k-block reads as zero
   }
   auto issue = [&](int kb, int buf) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
+      if (w * 6 + i >= NT) continue;             // wave-uniform
       const int kk = kb + tshift[i];
-      const unsigned char* g = (tbase[i] && kk >= 0 && kk < tnkb[i]) ? tbase[i] + (size_t)kk * tstride[i] : g_tp_zero;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + lane * 16), (lds_ptr_t)(lds + buf * BUF_BYTES + (w * 6 + i) * TPB), 16, 0, 0);
+      const uint64_t g = ((unsigned)kk < (unsigned)tnkb[i]) ? tbase[i] + (uint64_t)kk * (3 * TPB) : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + lane * 16), (lds_ptr_t)(lds + buf * BUFB + (w * 6 + i) * TPB), 16, 0, 0);
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[TMW][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int foff = tp_slot(lane & 31, lane >> 5);
+  auto chain6 = [](f32x16 c, const bf16x8 (&x)[3], const bf16x8 (&y)[3]) {   // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
+    return c;
+  };
+  bf16x8 a[TMW][3], b[2][3];
+  auto load_a = [&](int buf, int i) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(lds + buf * BUFB + foff + ((wm * TMW + i) * 3 + q) * TPB);
+  };
+  auto load_b = [&](int buf, int j) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(lds + buf * BUFB + foff + (NA3 + (wn * 2 + j) * 3 + q) * TPB);
+  };
 #if NASR_TP_NBUF == 2
   if (kb0 < kb1) issue(kb0, 0);
   for (int kb = kb0; kb < kb1; ++kb) {
@@ -165,51 +194,61 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's tiles of step kb have landed ...
     __syncthreads();                                    // ... and everybody's; buffer buf^1 is no longer being read
     if (kb + 1 < kb1) issue(kb + 1, buf ^ 1);
-#else
-  // experiment (see NASR_TP_NBUF): three buffers, two k-steps of DMA in flight.  Counted vmcnt (6 DMAs per wave and
-  // step) and a raw s_barrier: a __syncthreads() would drain the DMA queue (vmcnt(0)).
-  if (kb0 < kb1) issue(kb0, 0);
-  if (kb0 + 1 < kb1) issue(kb0 + 1, 1);
-  int buf = 0;
-  for (int kb = kb0; kb < kb1; ++kb) {
-    if (kb + 1 < kb1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the newest step's tiles have landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // everybody's; the buffer read in step kb-1 is free again
-    asm volatile("" ::: "memory");
-    if (kb + 2 < kb1) issue(kb + 2, buf >= 1 ? buf - 1 : 2);
-#endif
-    const unsigned char* ab = lds + buf * BUF_BYTES + foff;
-    bf16x8 a[4][3], b[2][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMW; ++i) load_a(buf, i);
+    load_b(buf, 0); load_b(buf, 1);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(ab + (((wm * 4 + i) * 3 + q) * TPB));
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(ab + ((24 + (wn * 2 + j) * 3 + q) * TPB));
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];       // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
-#if NASR_TP_NBUF != 2
-    buf = buf == 2 ? 0 : buf + 1;
-#endif
+      for (int j = 0; j < 2; ++j) acc[i][j] = chain6(acc[i][j], a[i], b[j]);
   }
+#else
+  // three LDS buffers: the DMA runs two k-steps ahead and the fragments of step k+1 are read from LDS WHILE the MFMAs of
+  // step k run, into the registers of fragments that have just had their last use (b[0] after the first column pass,
+  // a[i] after its second, b[1] at the end) - no extra registers, and the matrix pipe does not idle after the barrier.
+  int buf = 0;                                          // holds step kb
+  if (kb0 < kb1) {
+    issue(kb0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kb0 + 1 < kb1) issue(kb0 + 1, 1);
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) load_a(0, i);
+    load_b(0, 0); load_b(0, 1);
+  }
+  for (int kb = kb0; kb < kb1; ++kb) {
+    const int nb = buf == 2 ? 0 : buf + 1;              // holds step kb + 1 once its DMA has landed
+    const int fb = nb == 2 ? 0 : nb + 1;                // held step kb - 1: every wave read it during step kb - 2 ... kb - 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my tiles of step kb + 1 (issued one iteration ago) have landed
+    __builtin_amdgcn_s_barrier();                       // ... and everybody's
+    asm volatile("" ::: "memory");
+    if (kb + 2 < kb1) issue(kb + 2, fb);
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) acc[i][0] = chain6(acc[i][0], a[i], b[0]);
+    load_b(nb, 0);
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+      acc[i][1] = chain6(acc[i][1], a[i], b[1]);
+      load_a(nb, i);
+    }
+    load_b(nb, 1);
+    // pin that interleaving (the scheduler would otherwise cluster the 18 LDS reads behind the 48 MFMAs)
+    __builtin_amdgcn_sched_group_barrier(0x008, 6 * TMW, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    buf = nb;
+  }
+#endif
 
   // epilogue: C/D map of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < TMW; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int col = n0 + wn * 64 + 32 * ni + li;
@@ -217,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
       const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 128 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + wm * (32 * TMW) + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= p.M) continue;
         if (p.split_k > 1) p.slabs[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[mi][ni][r];
         else p.C[(size_t)row * p.ldc + col] = acc[mi][ni][r] + bv;
@@ -226,17 +265,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
 }
 
 hipError_t gemm_tp_prepare() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             GEMM_TP_LDS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tp_kernel<4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_TP_LDS);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tp_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM_TP_LDS);
+  return e;
 }
 
-// split so that the grid has >= ~256 blocks (one per CU) while every slice keeps >= 16 k-steps
+// 192-row block tiles where 256-row tiles would leave more than a tenth of their rows empty
+int gemm_tp_tile_rows(int M) {
+  const int w256 = (M + 255) / 256 * 256 - M, w192 = (M + 191) / 192 * 192 - M;
+  return (10 * w256 > M && w192 < w256) ? 192 : 256;
+}
+
+// K split by a cost model in units of one k-step of one block (measured 2.6 us for the 256-row tile whether one or two
+// blocks share a CU: they share its MFMA pipes): blocks run in rounds of 256 (one per CU), every slice keeps >= 16
+// k-steps, and each slab costs a write + a read of M x N floats at ~4 TB/s.
 int gemm_tp_pick_split(int M, int N, int K) {
-  const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  const int tm = gemm_tp_tile_rows(M);
+  const int tiles = ((M + tm - 1) / tm) * ((N + 255) / 256);
   const int kbs = (K + 15) / 16;
-  int s = 1;
-  while (tiles * s < 256 && kbs / (2 * s) >= 16) s *= 2;
-  return s;
+  const double kstep = 2.6e-6 * tm / 256.0;
+  const double slab = (double)M * N * 8.0 / 4e12 / kstep;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 64; ++s) {
+    if (s > 1 && kbs / s < 16) break;
+    const int per = (kbs + s - 1) / s;
+    const int rounds = (tiles * s + 255) / 256;
+    const double cost = (double)rounds * per + (s > 1 ? s * slab : 0.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  return best;
 }
 
 void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st) {
@@ -250,8 +311,10 @@ void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st) {
   p.kb_chunk = per;
   p.split_k = (p.kbs + per - 1) / per;
   p.slabs = g.slabs;
-  dim3 grid((g.N + 255) / 256, (g.M + 255) / 256, p.split_k);
-  hipLaunchKernelGGL(gemm_tp_kernel, grid, dim3(512), GEMM_TP_LDS, st, p);
+  const int tm = g.tile_rows ? g.tile_rows : gemm_tp_tile_rows(g.M);
+  dim3 grid((g.N + 255) / 256, (g.M + tm - 1) / tm, p.split_k);
+  if (tm == 192) hipLaunchKernelGGL(gemm_tp_kernel<3>, grid, dim3(512), GEMM_TP_LDS, st, p);
+  else hipLaunchKernelGGL(gemm_tp_kernel<4>, grid, dim3(512), GEMM_TP_LDS, st, p);
   if (p.split_k > 1) launch_reduce_slabs(g.slabs, p.split_k, (int64_t)g.M * g.N, g.C, st);   // needs ldc == N, no bias
 }
 

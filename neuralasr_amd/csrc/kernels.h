@@ -63,8 +63,10 @@ struct GemmTPDesc {
   const float* bias;        // per-n, only with split_k == 1
   int split_k;              // > 1: partial slabs + reduction; needs ldc == N and no bias
   float* slabs;             // split_k * M * N floats
+  int tile_rows;            // 0: gemm_tp_tile_rows(M); 192 / 256 forces the block tile (tools/gemmbench.hip)
 };
 hipError_t gemm_tp_prepare();    // once per process: raise the kernel's dynamic-LDS limit
+int gemm_tp_tile_rows(int M);
 int gemm_tp_pick_split(int M, int N, int K);
 void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st);
 

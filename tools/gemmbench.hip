@@ -50,7 +50,8 @@ int main() {
   const size_t nX = (size_t)R * 1024, nG = (size_t)R * 4096, nW = (size_t)1024 * 4096;
   std::vector<NT> nts = {{"xproj  NT 8000x4096x576 ", R, 4096, 576, 1, X, nX, W, nW}, {"xproj  NT 8000x4096x1024", R, 4096, 1024, 1, X, nX, W, nW},
                          {"dX     NT 8000x1024x4096", R, 1024, 4096, 1, G, nG, W, nW}, {"dWx    NT 576x4096x8000 ", 576, 4096, R, 4, X, nX, G, nG},
-                         {"dWx    NT 1024x4096x8000", 1024, 4096, R, 2, X, nX, G, nG}, {"dU     NT 512x2048x8000 ", 512, 2048, R, 8, X, nX, G, nG}};
+                         {"dWx    NT 1024x4096x8000", 1024, 4096, R, 2, X, nX, G, nG}, {"dU     NT 512x2048x8000 ", 512, 2048, R, 8, X, nX, G, nG},
+                         {"odd    NT 1100x1024x4096", 1100, 1024, 4096, 1, G, nG, W, nW}};   // 192-row tiles, ragged last block row
   float* O2 = dev_rand((size_t)R * 4096);
   for (auto& c : nts) {
     // operands: A [M][K] = X viewed with lda = K, B [N][K] = G viewed with ldb = K (both buffers are large enough)
@@ -106,6 +107,22 @@ int main() {
     }
     printf("tp     %s split %d : %.3f ms  %.1f TF-equiv (+ %.3f ms to split both operands)  rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, split, best,
            2.0 * c.M * c.N * c.K / best / 1e9, tsplit, sqrt(num / den), mx);
+  }
+  // block-tile height x K split for the layer-0 weight gradient (M = 576 = 2.25 x 256 = 3 x 192)
+  {
+    launch_tp_split(X, TA, 576, R, R, false, st); launch_tp_split(G, TB, 4096, R, R, false, st);
+    for (int tm : {256, 192})
+      for (int split : {4, 5, 6, 8, 10}) {
+        GemmTPDesc g{}; g.A = TA; g.B = TB; g.C = O; g.M = 576; g.N = 4096; g.K = R; g.nkbA = (R + 15) / 16; g.nkbB = g.nkbA; g.ldc = 4096;
+        g.split_k = split; g.slabs = slabs; g.tile_rows = tm;
+        launch_gemm_tp(g, st); CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+        float best = 1e9f;
+        for (int i = 0; i < 10; ++i) {
+          CK(hipEventRecord(a, st)); launch_gemm_tp(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+          float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+        }
+        printf("sweep  dWx 576x4096x8000 tile rows %d split %2d : %.3f ms\n", tm, split, best);
+      }
   }
   // transposed split: TP from a [K][rows] source must equal TP from the explicit transpose
   {
