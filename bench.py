@@ -138,6 +138,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--per-step', action='store_true', help='per-timestep launches (lstm.hip) instead of the persistent recurrence')
+    ap.add_argument('--allreduce', default='auto', choices=['auto', 'bucketed', 'single'],
+                    help='N > 1: gradient exchange as one all-reduce after the backward pass, or per-layer buckets on a '
+                         'side stream under the rest of the backward pass; auto times both during warm-up')
     args = ap.parse_args()
 
     import torch
@@ -180,10 +183,19 @@ def main():
     frames = eng.resident_frames()
     gt = eng.grad_tensor() if use_dist else None
 
+    reducer = None
+    if use_dist:
+        from neuralasr_amd.parallel import BucketedAllReduce
+        reducer = BucketedAllReduce(eng, dist, gt)
+    ar_mode = 'single' if (args.allreduce == 'single' or world == 1 or len(eng.grad_buckets()) == 1) else 'bucketed'
+
     def step():
         eng.compute_grads()
         if use_dist:
-            dist.all_reduce(gt, op=dist.ReduceOp.SUM)
+            if ar_mode == 'bucketed':
+                reducer.all_reduce()
+            else:
+                dist.all_reduce(gt, op=dist.ReduceOp.SUM)
         eng.apply_adam(1.0 / world)
 
     def fence():
@@ -191,6 +203,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ar_probe = None
+    if use_dist and world > 1 and args.allreduce == 'auto' and ar_mode == 'bucketed':
+        # measure, don't guess: a few untimed steps each way (part of the warm-up), slowest rank decides for everybody
+        probe = {}
+        for mode in ('single', 'bucketed'):
+            ar_mode = mode
+            step(); step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                step()
+            fence()
+            tt = torch.tensor([(time.perf_counter() - t0) / 4], device='cuda', dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            probe[mode] = float(tt.item()) * 1e3
+        ar_mode = 'bucketed' if probe['bucketed'] <= probe['single'] else 'single'
+        ar_probe = probe
     for _ in range(args.warmup):
         step()
     fence()
@@ -296,7 +325,8 @@ def main():
                                    + (', ragged lengths' if args.var_len else ''),
                        'batch_per_gpu': B, 'frames': T, 'var_len': bool(args.var_len),
                        'parallelism': f'dp{world}', 'hipgraph': not args.no_graph,
-                       'recurrence': eng.recurrence_mode},
+                       'recurrence': eng.recurrence_mode,
+                       'allreduce': (ar_mode if world > 1 else None)},
             'loss': loss,
             'roofline': {'bound': 'hbm', 'kernel': kname,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -318,7 +348,11 @@ def main():
             gbytes = gt.numel() * 4 / 1e9
             out['allreduce'] = {'ms': ar_ms, 'bytes': gt.numel() * 4,
                                 'bus_GBps': 2.0 * (world - 1) / world * gbytes / (ar_ms * 1e-3),
-                                'xgmi_peak_GBps': 7 * 153.0}
+                                'xgmi_peak_GBps': 7 * 153.0, 'mode': ar_mode, 'buckets': len(eng.grad_buckets()),
+                                'probe_ms_per_step': ar_probe,
+                                'note': 'ms / bus_GBps: ONE all-reduce of the whole buffer, timed alone; mode = how the '
+                                        'timed steps exchange gradients (bucketed: per-layer buckets on a side stream '
+                                        'under the rest of the backward pass)'}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, B, 1234)
         else:

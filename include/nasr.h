@@ -132,10 +132,19 @@ int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len
  *   nasr_upload_batch(shard) ; nasr_compute_grads ; all-reduce(sum) nasr_grad_device_ptr over
  *   RCCL ; nasr_apply_adam(1/world) ; nasr_get_loss
  * The gradient buffer is one flat fp32 device array of nasr_grad_device_count elements in the
- * library's padded internal layout (identical on every rank; padding elements are always 0).  Its last 32
+ * library's padded internal layout (identical on every rank; padding elements are always 0).  Its first 32
  * floats are not gradients: the first of them is the step's FAULT word (0, or 1 when this rank's persistent
  * recurrence gave up).  Reduce the whole array: a non-zero sum makes nasr_apply_adam a no-op on every rank and
- * nasr_get_loss return NASR_ERR_HIP ("step void"), so the replicas never diverge. */
+ * nasr_get_loss return NASR_ERR_HIP ("step void"), so the replicas never diverge.
+ *
+ * Overlapping the exchange with the backward pass (the reference's towers cannot: average_gradients waits for
+ * every tower's full gradient list, tfnetwork.py:72-86): the array is cut into nasr_grad_bucket_count()
+ * contiguous buckets in the order nasr_compute_grads completes them (top LSTM layer + W + b first, then one per
+ * layer going down, the bottom layer + the fault word last; a one-layer net has one bucket).
+ * nasr_grad_bucket(i) gives bucket i's [offset, offset + count) in floats from nasr_grad_device_ptr();
+ * nasr_grad_bucket_wait(i, s) makes HIP stream s wait until the nasr_compute_grads call issued before it has
+ * finished bucket i (no host sync).  All-reduce bucket i on s after that wait, for i = 0 .. count-1, then make the
+ * handle's stream wait for s before nasr_apply_adam.  The buckets cover the whole array exactly once. */
 int nasr_upload_batch(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
                       const int32_t* label_len, int B, int T, int Lmax);
 /* Same, but the context stacking of utils.py:8-21 (include_context) happens on the device: `centre` is the
@@ -149,6 +158,9 @@ int nasr_upload_batch_context(nasr_handle h, const float* centre, const float* p
 int nasr_compute_grads(nasr_handle h);          /* forward+CTC+backward on the resident batch (async) */
 void* nasr_grad_device_ptr(nasr_handle h);
 int64_t nasr_grad_device_count(nasr_handle h);
+int nasr_grad_bucket_count(nasr_handle h);
+int nasr_grad_bucket(nasr_handle h, int i, int64_t* offset, int64_t* count);
+int nasr_grad_bucket_wait(nasr_handle h, int i, void* hip_stream);
 int nasr_apply_adam(nasr_handle h, float grad_scale); /* g*grad_scale, TF Adam, step += 1 (async) */
 /* copy the gradients out (TF order) / load externally reduced gradients (TF order) for nasr_apply_adam:
  * the single-process form of average_gradients (several towers time-sliced on one GPU). */

@@ -22,7 +22,8 @@ SYMBOLS = [
     'nasr_num_tensors', 'nasr_tensor_info', 'nasr_set_params', 'nasr_get_params', 'nasr_set_adam_state',
     'nasr_get_adam_state', 'nasr_set_learning_rate', 'nasr_train_step', 'nasr_forward', 'nasr_logit_frames',
     'nasr_loss', 'nasr_loss_and_grads', 'nasr_greedy_decode', 'nasr_upload_batch', 'nasr_compute_grads',
-    'nasr_grad_device_ptr', 'nasr_grad_device_count', 'nasr_apply_adam', 'nasr_get_grads', 'nasr_set_grads',
+    'nasr_grad_device_ptr', 'nasr_grad_device_count', 'nasr_grad_bucket_count', 'nasr_grad_bucket',
+    'nasr_grad_bucket_wait', 'nasr_apply_adam', 'nasr_get_grads', 'nasr_set_grads',
     'nasr_upload_batch_context', 'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_ctc_beam_search', 'nasr_get_loss', 'nasr_resident_frames',
     'nasr_set_profiling', 'nasr_get_phase_times', 'nasr_set_graph_mode',
     'nasr_get_recurrence_mode', 'nasr_set_recurrence_mode', 'nasr_set_dropout_state', 'nasr_get_dropout_state',
@@ -96,6 +97,9 @@ def load():
         'nasr_compute_grads': (c_int, [H]),
         'nasr_grad_device_ptr': (c_void_p, [H]),
         'nasr_grad_device_count': (c_int64, [H]),
+        'nasr_grad_bucket_count': (c_int, [H]),
+        'nasr_grad_bucket': (c_int, [H, c_int, POINTER(c_int64), POINTER(c_int64)]),
+        'nasr_grad_bucket_wait': (c_int, [H, c_int, c_void_p]),
         'nasr_apply_adam': (c_int, [H, c_float]),
         'nasr_get_grads': (c_int, [H, fp, c_int64]),
         'nasr_set_grads': (c_int, [H, fp, c_int64]),

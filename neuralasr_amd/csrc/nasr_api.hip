@@ -57,7 +57,8 @@ struct TensorInfo {
 enum Phase { PH_PACK = 0, PH_XPROJ, PH_RECF, PH_PROJCTC, PH_PROJB, PH_RECB, PH_WGRAD, PH_ADAM, PH_COUNT };
 
 constexpr int PIPE_MAX_CHUNKS = 16;
-constexpr int GRAD_TAIL = 32;   // floats behind the gradients; [0] = fault word of the step
+constexpr int GRAD_HEAD = 32;   // floats in front of the gradients (h->G = h->Gbase + GRAD_HEAD); [0] = fault word of the step
+constexpr int MAX_BUCKETS = 16;
 
 struct GraphKey {
   int T, l, bwd, s0;
@@ -127,6 +128,11 @@ struct nasr_ctx {
   uint32_t drop_seed = 4567u, drop_counter = 0;   // random_seed of networks/deepspeech.py:26
 
   float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *Uf = nullptr, *Ub = nullptr;
+  float* Gbase = nullptr;                    // allocation behind G: [GRAD_HEAD floats, [0] = fault word][np_int gradients]
+  // gradient buckets: (offset, count) in floats from Gbase, in the order backward() completes them; one event each
+  std::vector<std::pair<int64_t, int64_t>> buckets;
+  std::vector<hipEvent_t> ev_bucket;
+  std::vector<int> bucket_of_layer;          // LSTM layer -> bucket whose last gradients are that layer's (-1: none)
   float* WxT = nullptr;                // per layer [D*N4][Ip]: transposed input weights (K-contiguous B operand)
   std::vector<int64_t> off_wxt;
   int64_t adam_step = 0;
@@ -618,11 +624,11 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
     const size_t k = (size_t)l * h->D;
     if (!bwd)
       launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->gates[l].as<float>(), h->cbuf[l].as<float>(),
-                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->G + h->np_int,
+                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->Gbase,
                               h->cfg.forget_bias, st);
     else
       launch_lstm_persist_bwd(dm, h->Upb + k * h->imb, h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(),
-                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->G + h->np_int, st);
+                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->Gbase, st);
     h->persist_used = true;
     HIPCHK(h, hipGetLastError());
     return NASR_OK;
@@ -1050,6 +1056,7 @@ int backward(nasr_ctx* h) {
       if (l > 0 || h->npre > 0) gemm_dx(h, l, 0, R, h->st);   // critical path first
       int rc = weight_grads(h, l);
       if (rc) return rc;
+      if (h->bucket_of_layer[l] >= 0) HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
     }
   } else {
     // BPTT of layer l on chunk c needs dOut_l[chunk c] = dX GEMM of layer l+1's chunk c, and its own chunk c+1
@@ -1078,6 +1085,7 @@ int backward(nasr_ctx* h) {
     for (int l = h->L - 1; l >= 0; --l) {
       int rc = weight_grads(h, l);
       if (rc) return rc;
+      if (h->bucket_of_layer[l] >= 0) HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
     }
   }
   for (int i = h->npre - 1; i >= 0; --i) {
@@ -1086,6 +1094,7 @@ int backward(nasr_ctx* h) {
                             i > 0 ? h->dYbuf[i - 1].as<float>() : nullptr);
     if (rc) return rc;
   }
+  HIPCHK(h, hipEventRecord(h->ev_bucket.back(), h->st));   // the bucket with the fault word: nothing of the step is left
   h->have_grads = true;
   return NASR_OK;
 }
@@ -1224,15 +1233,37 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       return bail(NASR_ERR_HIP, "hipMalloc of transposed weights failed");
   }
   const size_t nb = (size_t)h->np_int * 4;
-  const size_t gb = nb + GRAD_TAIL * 4;   // the gradient buffer ends with the fault word (+ padding): see nasr_grad_device_count
+  const size_t gb = nb + GRAD_HEAD * 4;   // the gradient buffer starts with the fault word (+ padding): see nasr_grad_device_count
   const size_t ub = (size_t)h->L * h->D * h->Hp * h->N4 * 4;
   if (hipMalloc(&h->P, nb) != hipSuccess || hipMalloc(&h->M, nb) != hipSuccess || hipMalloc(&h->V, nb) != hipSuccess ||
-      hipMalloc(&h->G, gb) != hipSuccess || hipMalloc(&h->Uf, ub) != hipSuccess || hipMalloc(&h->Ub, ub) != hipSuccess)
+      hipMalloc(&h->Gbase, gb) != hipSuccess || hipMalloc(&h->Uf, ub) != hipSuccess || hipMalloc(&h->Ub, ub) != hipSuccess)
     return bail(NASR_ERR_HIP, "hipMalloc of parameter buffers failed");
   (void)hipMemsetAsync(h->P, 0, nb, h->st);
   (void)hipMemsetAsync(h->M, 0, nb, h->st);
   (void)hipMemsetAsync(h->V, 0, nb, h->st);
-  (void)hipMemsetAsync(h->G, 0, gb, h->st);
+  h->G = h->Gbase + GRAD_HEAD;
+  (void)hipMemsetAsync(h->Gbase, 0, gb, h->st);
+  {
+    // Buckets for an all-reduce that overlaps the rest of the backward pass (nasr_grad_bucket*): the internal layout
+    // is [head | dense stages | layer 0 | ... | layer L-1 | W | b] and backward() finishes W, b first, then the layers
+    // from the top down, then the dense stages in front of the stack.  Bucket 0 = layer L-1 + W + b, then one bucket
+    // per layer down to layer 1, and a last one with everything in front of layer 1 INCLUDING the fault word, which
+    // any launch of the step may still raise.  A one-layer net has a single bucket.
+    h->bucket_of_layer.assign(h->L, -1);
+    if (h->L > 1 && h->L <= MAX_BUCKETS) {
+      for (int l = h->L - 1; l >= 1; --l) {
+        const int64_t lo = h->off_wx[l], hi = l == h->L - 1 ? h->np_int : h->off_wx[l + 1];
+        h->bucket_of_layer[l] = (int)h->buckets.size();
+        h->buckets.push_back({GRAD_HEAD + lo, hi - lo});
+      }
+      h->buckets.push_back({0, GRAD_HEAD + h->off_wx[1]});
+    } else {
+      h->buckets.push_back({0, GRAD_HEAD + h->np_int});
+    }
+    h->ev_bucket.resize(h->buckets.size());
+    for (auto& e2 : h->ev_bucket)
+      if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) return bail(NASR_ERR_HIP, "hipEventCreate failed");
+  }
   (void)hipMemsetAsync(h->Uf, 0, ub, h->st);
   (void)hipMemsetAsync(h->Ub, 0, ub, h->st);
   {
@@ -1328,8 +1359,9 @@ int nasr_destroy(nasr_handle h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (hipEvent_t e : h->ev_done) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_dx) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_bucket) (void)hipEventDestroy(e);
   drop_graphs(h);
-  for (float* p : {h->P, h->M, h->V, h->G, h->Uf, h->Ub, h->WxT, h->Upf, h->Upb, h->xch})
+  for (float* p : {h->P, h->M, h->V, h->Gbase, h->Uf, h->Ub, h->WxT, h->Upf, h->Upb, h->xch})
     if (p) (void)hipFree(p);
   if (h->WfTP) (void)hipFree(h->WfTP);
   if (h->WbTP) (void)hipFree(h->WbTP);
@@ -1461,7 +1493,7 @@ int nasr_compute_grads(nasr_handle h) {
     h->window_open = true;
     h->total_valid = false;
   }
-  HIPCHK(h, hipMemsetAsync(h->G + h->np_int, 0, GRAD_TAIL * 4, h->st));   // the step's fault word
+  HIPCHK(h, hipMemsetAsync(h->Gbase, 0, GRAD_HEAD * 4, h->st));   // the step's fault word
   int rc = forward(h);
   if (rc) return rc;
   rc = ctc_forward(h);
@@ -1469,8 +1501,25 @@ int nasr_compute_grads(nasr_handle h) {
   return backward(h);
 }
 
-void* nasr_grad_device_ptr(nasr_handle h) { return h ? h->G : nullptr; }
-int64_t nasr_grad_device_count(nasr_handle h) { return h ? h->np_int + GRAD_TAIL : -1; }
+void* nasr_grad_device_ptr(nasr_handle h) { return h ? h->Gbase : nullptr; }
+int64_t nasr_grad_device_count(nasr_handle h) { return h ? h->np_int + GRAD_HEAD : -1; }
+
+int nasr_grad_bucket_count(nasr_handle h) { return h ? (int)h->buckets.size() : NASR_ERR_ARG; }
+
+int nasr_grad_bucket(nasr_handle h, int i, int64_t* offset, int64_t* count) {
+  if (!h) return NASR_ERR_ARG;
+  if (i < 0 || i >= (int)h->buckets.size() || !offset || !count) return h->fail(NASR_ERR_ARG, "nasr_grad_bucket: bad index");
+  *offset = h->buckets[i].first;
+  *count = h->buckets[i].second;
+  return NASR_OK;
+}
+
+int nasr_grad_bucket_wait(nasr_handle h, int i, void* hip_stream) {
+  if (!h) return NASR_ERR_ARG;
+  if (i < 0 || i >= (int)h->buckets.size()) return h->fail(NASR_ERR_ARG, "nasr_grad_bucket_wait: bad index");
+  HIPCHK(h, hipStreamWaitEvent((hipStream_t)hip_stream, h->ev_bucket[i], 0));
+  return NASR_OK;
+}
 
 int nasr_apply_adam(nasr_handle h, float grad_scale) {
   if (!h) return NASR_ERR_ARG;
@@ -1484,7 +1533,7 @@ int nasr_apply_adam(nasr_handle h, float grad_scale) {
     const double lr_t = (double)h->lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_step)) /
                         (1.0 - std::pow(b1, (double)h->adam_step));
     launch_adam(h->P, h->M, h->V, h->G, h->np_int, (float)lr_t, h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, grad_scale,
-                h->G + h->np_int, h->st);
+                h->Gbase, h->st);
     int rc = repack(h);
     if (rc) return rc;
   }
@@ -1511,7 +1560,7 @@ int nasr_set_grads(nasr_handle h, const float* flat, int64_t n) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = scatter_to_device(h, flat, h->G);
   if (rc) return rc;
-  HIPCHK(h, hipMemsetAsync(h->G + h->np_int, 0, GRAD_TAIL * 4, h->st));
+  HIPCHK(h, hipMemsetAsync(h->Gbase, 0, GRAD_HEAD * 4, h->st));
   h->have_grads = true;
   return NASR_OK;
 }
@@ -1553,7 +1602,7 @@ int nasr_get_loss(nasr_handle h, float* loss_out) {
   // recurrence gave up, every rank's Adam launch of that step was a no-op (optim.hip) and the step is void everywhere
   float fault = 0.f;
   HIPCHK(h, hipMemcpyAsync(loss_out, h->loss.p, 4, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipMemcpyAsync(&fault, h->G + h->np_int, 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(&fault, h->Gbase, 4, hipMemcpyDeviceToHost, h->st));
   const int rc = sync_checked(h);
   if (fault != 0.f) {
     h->adam_step -= std::min<int64_t>(h->adam_unverified, h->adam_step);
@@ -1569,7 +1618,7 @@ int nasr_get_loss(nasr_handle h, float* loss_out) {
 int nasr_step_void(nasr_handle h, int* void_out) {
   if (!h || !void_out) return NASR_ERR_ARG;
   float fault = 0.f;
-  HIPCHK(h, hipMemcpyAsync(&fault, h->G + h->np_int, 4, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(&fault, h->Gbase, 4, hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipStreamSynchronize(h->st));
   (void)persist_check(h);   // a local abort: switch this handle to the per-step kernels (the message stays in last_error)
   *void_out = fault != 0.f ? 1 : 0;

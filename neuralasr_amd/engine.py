@@ -285,6 +285,23 @@ class Engine:
                                         'strides': None}
         return torch.as_tensor(_Ext(), device='cuda')
 
+    def grad_buckets(self):
+        """[(offset, count)] in floats from grad_device_ptr(): contiguous pieces of the gradient buffer in the order
+        compute_grads() completes them (include/nasr.h, "Overlapping the exchange")."""
+        out = []
+        n = self.lib.nasr_grad_bucket_count(self.h)
+        if n < 0:
+            self._ck(n)
+        for i in range(n):
+            o, c = c_int64(), c_int64()
+            self._ck(self.lib.nasr_grad_bucket(self.h, i, byref(o), byref(c)))
+            out.append((int(o.value), int(c.value)))
+        return out
+
+    def bucket_wait(self, i, stream):
+        """Makes HIP stream `stream` (raw handle) wait until the compute_grads() issued before has completed bucket i."""
+        self._ck(self.lib.nasr_grad_bucket_wait(self.h, int(i), c_void_p(int(stream))))
+
     # ------------------------------------------------------------------ measurement
     def set_profiling(self, on):
         self._ck(self.lib.nasr_set_profiling(self.h, int(bool(on))))

@@ -51,6 +51,7 @@ class HipNetwork(Network):
     train_ler_decoder = 'greedy'             # mean_ler of train(): greedy on the step's own logits
     beam_width = 100
     device_context = True                    # rebuild include_context's stacking on the GPU (1/(2c+1) of the H2D bytes)
+    bucketed_allreduce = True                # one process per GPU: exchange per-layer gradient buckets under the backward pass
 
     def __init__(self, config, fortraining=False):
         Network.__init__(self)
@@ -73,6 +74,7 @@ class HipNetwork(Network):
         self.engine.set_step_decode(True)
         self.engine.set_params(self.initial_params(self.engine.tensors(), seed=1))
         self._grad_tensor = None
+        self._reducer = None
         self.global_step = self.config.start_step
         self.load_checkpoint(self.global_step if fortraining else 1, self.config.model_dir)
         if fortraining and self.coll.rank == 0:
@@ -177,6 +179,7 @@ class HipNetwork(Network):
         from .._lib import NasrError
         n, mine = self._towers()
         losses, lers, gsum = [], [], None
+        reduced = False
         for k in mine:
             f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, k)
             ctx = getattr(self.config, 'numcontext', 0)
@@ -184,10 +187,19 @@ class HipNetwork(Network):
                     self.engine.upload_batch_context(f, s, l, ll, ctx, self.config.numcep)):
                 self.engine.upload_batch(f, s, l, ll)
             self.engine.compute_grads()
+            if self.coll.world > 1 and self.bucketed_allreduce:
+                # enqueue the exchange NOW, before the host waits for the loss: bucket i goes out as soon as the backward
+                # pass has finished it, under the BPTT of the layers below
+                if self._grad_tensor is None:
+                    self._grad_tensor = self.engine.grad_tensor()
+                    self._reducer = self.coll.bucketed(self.engine, self._grad_tensor)
+                if self._reducer is not None:
+                    self._reducer.all_reduce()
+                    reduced = True
             try:
                 losses.append(self.engine.get_loss())
             except NasrError as exc:            # keep the collective protocol going; the step is repeated by train()
-                if 'persistent recurrence aborted' not in str(exc):
+                if 'persistent recurrence aborted' not in str(exc) and 'training step is void' not in str(exc):
                     raise
                 if self.coll.world == 1:
                     return None                 # single process: nothing else to keep in step, just repeat
@@ -202,9 +214,10 @@ class HipNetwork(Network):
             self.engine.set_grads((gsum / n).astype(np.float32))
             self.engine.apply_adam(1.0)
         elif self.coll.world > 1:               # one tower per GPU: RCCL all-reduce of the flat buffer
-            if self._grad_tensor is None:
-                self._grad_tensor = self.engine.grad_tensor()
-            self.coll.all_reduce_sum_(self._grad_tensor)
+            if not reduced:
+                if self._grad_tensor is None:
+                    self._grad_tensor = self.engine.grad_tensor()
+                self.coll.all_reduce_sum_(self._grad_tensor)
             self.engine.apply_adam(1.0 / n)
         else:
             self.engine.apply_adam(1.0)

@@ -48,6 +48,13 @@ class Collective:
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
         return tensor
 
+    def bucketed(self, engine, grad_tensor):
+        """A BucketedAllReduce over this process group (None when the buffer is a single bucket or the backend
+        cannot run collectives on device streams)."""
+        if not self.dist or self.dist.get_backend() != 'nccl' or len(engine.grad_buckets()) < 2:
+            return None
+        return BucketedAllReduce(engine, self.dist, grad_tensor)
+
     def mean_scalars(self, values, device=None):
         """mean over ranks of a few python floats (loss, ler): the reduce_mean of tfnetwork.py:135-136."""
         if not self.dist:
@@ -56,3 +63,39 @@ class Collective:
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or 'cpu')
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [float(x) / self.world for x in t.tolist()]
+
+
+class BucketedAllReduce:
+    """Sum all-reduce of an engine's gradient buffer, bucket by bucket, on a side stream that waits for each bucket's
+    completion event: the exchange of the upper layers' gradients runs under the BPTT and weight-gradient GEMMs of the
+    layers below (the reference's average_gradients, tfnetwork.py:72-86, can only start when every tower's backward pass
+    has ended).  Usage per step, with the engine's stream current:
+
+        engine.compute_grads(); reducer.all_reduce(); engine.apply_adam(1 / world)
+
+    all_reduce() returns once the collectives are ENQUEUED; the current stream has been made to wait for them.
+    xGMI is point-to-point and a ring is per-link bound, so the buckets stay large: one per LSTM layer (8-21 MB at
+    2x500), never per tensor."""
+
+    def __init__(self, engine, dist, grad_tensor=None):
+        import torch
+        self.torch, self.dist, self.engine = torch, dist, engine
+        self.tensor = engine.grad_tensor() if grad_tensor is None else grad_tensor
+        self.buckets = engine.grad_buckets()
+        covered = sorted(self.buckets)
+        if covered[0][0] != 0 or sum(c for _, c in covered) != self.tensor.numel() or \
+                any(a[0] + a[1] != b[0] for a, b in zip(covered, covered[1:])):
+            raise RuntimeError('gradient buckets do not tile the gradient buffer: %r' % (self.buckets,))
+        self.views = [self.tensor[o:o + c] for o, c in self.buckets]
+        self.stream = torch.cuda.Stream(device=self.tensor.device)
+
+    def all_reduce(self):
+        works = []
+        with self.torch.cuda.stream(self.stream):
+            for i, v in enumerate(self.views):
+                self.engine.bucket_wait(i, self.stream.cuda_stream)
+                works.append(self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()            # orders the CURRENT stream (the engine's) behind the collective; no host sync
+        return self.tensor
+

@@ -178,6 +178,33 @@ def test_rccl_path_at_world_one_orders_with_the_engine_stream(tmp_path):
             dist.all_reduce(gt, op=dist.ReduceOp.SUM)
             e.apply_adam(1.0)
         np.testing.assert_array_equal(e.get_params(), ref.get_params())
+        # the same three steps with the exchange cut into per-layer buckets on a side stream (include/nasr.h,
+        # "Overlapping the exchange"): buckets tile the buffer, the fault word leads it, parameters come out identical
+        from neuralasr_amd.parallel import BucketedAllReduce, Collective
+        b = Engine(20, 48, 2, True, 'concat', 11, learning_rate=1e-3, stream=ts.cuda_stream)
+        b.set_params(p0)
+        red = Collective().bucketed(b, b.grad_tensor())
+        assert isinstance(red, BucketedAllReduce)
+        buckets = b.grad_buckets()
+        assert len(buckets) == 2 and buckets[-1][0] == 0 and buckets[0][0] == buckets[-1][1]
+        assert sum(c for _, c in buckets) == b.grad_device_ptr()[1]
+        for _ in range(3):
+            b.upload_batch(feats, seq_len, labels, label_len)
+            b.compute_grads()
+            red.all_reduce()
+            b.apply_adam(1.0)
+        assert not b.step_void()
+        np.testing.assert_array_equal(b.get_params(), ref.get_params())
+        # a side-stream reader that waited for bucket 0 sees the finished top-layer gradients of THIS compute_grads
+        b.upload_batch(feats, seq_len, labels, label_len)
+        b.compute_grads()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            b.bucket_wait(0, side.cuda_stream)
+            early = red.views[0].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(early, red.views[0]) and float(early.abs().sum()) > 0
+        b.close()
         # aliasing: scaling the torch view scales what the engine hands back
         e.upload_batch(feats, seq_len, labels, label_len)
         e.compute_grads()

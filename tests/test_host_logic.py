@@ -141,3 +141,13 @@ def test_bench_algorithmic_bytes_cover_the_dense_stages():
     assert sd.pre == (2048, 2048, 4096) and sd.post == 2048 and 'deepspeech' in name
     Ad, Wd, Rd = bench.algorithmic_bytes(sd, 32, 500)
     assert Ad > A and Wd == 40 * sd.param_count() and Rd == 2 * 500 * 2 * 4 * 2048 * 2048 * 4
+
+
+def test_collective_without_process_group_offers_no_bucketed_reducer():
+    """Single process (no torch.distributed group): the bucketed exchange is not offered, the plain path is used."""
+    from neuralasr_amd.parallel import Collective
+
+    class FakeEngine:
+        def grad_buckets(self):
+            return [(32, 10), (0, 32)]
+    assert Collective().bucketed(FakeEngine(), None) is None
