@@ -106,6 +106,75 @@ __global__ __launch_bounds__(256) void tp_split_kernel(const float* __restrict__
   *reinterpret_cast<bf16x8*>(dst + 2 * TPB) = p3;
 }
 
+// One pass over src [rows][K] (row stride ld) that writes BOTH plane sets: tpN = planes of src (row = src row, k = src
+// column) and tpT = planes of its transpose (row = src column, k = src row) - dG feeds the input-gradient GEMM in the
+// first form and the weight-gradient GEMMs in the second.  A block stages a 64 x 64 fp32 piece in LDS; grid
+// (ceil(K/64), ceil(rows/64)), 256 threads.
+__global__ __launch_bounds__(256) void tp_split2_kernel(const float* __restrict__ src, unsigned char* __restrict__ tpN,
+                                                        unsigned char* __restrict__ tpT, int rows, int K, int ld) {
+  __shared__ float tile[64][65];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int nkbN = (K + 15) / 16, nrbN = (rows + 31) / 32;
+  const int nkbT = (rows + 15) / 16, nrbT = (K + 31) / 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                   // 16 rows per pass, one float4 per thread
+    const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows) {
+      const float* s = src + (size_t)(r0 + r) * ld + c0 + c;
+      if (c0 + c + 4 <= K) v = *reinterpret_cast<const float4*>(s);
+      else {
+        if (c0 + c < K) v.x = s[0];
+        if (c0 + c + 1 < K) v.y = s[1];
+        if (c0 + c + 2 < K) v.z = s[2];
+      }
+    }
+    tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+  }
+  __syncthreads();
+  auto emit = [&](const float (&x)[8], unsigned char* dst) {
+    bf16x8 p1, p2, p3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h1 = (__bf16)x[e];
+      const float q1 = x[e] - (float)h1;
+      const __bf16 h2 = (__bf16)q1;
+      const float q2 = q1 - (float)h2;
+      p1[e] = h1; p2[e] = h2; p3[e] = (__bf16)q2;
+    }
+    *reinterpret_cast<bf16x8*>(dst) = p1;
+    *reinterpret_cast<bf16x8*>(dst + TPB) = p2;
+    *reinterpret_cast<bf16x8*>(dst + 2 * TPB) = p3;
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int g = t + 256 * i;                    // granule 0..511
+    float x[8];
+    {  // planes of src: granule = (row g >> 3, columns 8 (g & 7) ..)
+      const int r = g >> 3, c = g & 7;
+      const int row = r0 + r, kb = (c0 >> 4) + (c >> 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = tile[r][8 * c + e];
+      if ((row >> 5) < nrbN && kb < nkbN)
+        emit(x, tpN + ((size_t)(row >> 5) * nkbN + kb) * 3 * TPB + tp_slot(row & 31, c & 1));
+    }
+    {  // planes of the transpose: granule = (src column g & 63, src rows 8 (g >> 6) ..)
+      const int j = g & 63, c = g >> 6;
+      const int row = c0 + j, kb = (r0 >> 4) + (c >> 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = tile[8 * c + e][j];
+      if ((row >> 5) < nrbT && kb < nkbT)
+        emit(x, tpT + ((size_t)(row >> 5) * nkbT + kb) * 3 * TPB + tp_slot(row & 31, c & 1));
+    }
+  }
+}
+
+void launch_tp_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, hipStream_t st) {
+  dim3 grid((K + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(tp_split2_kernel, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld);
+}
+
 size_t tp_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 3 * TPB; }
 
 void launch_tp_split(const float* src, unsigned char* tp, int rows, int K, int ld, bool transposed, hipStream_t st) {

@@ -52,6 +52,8 @@ void launch_transpose(const float* in, float* out, int R, int C, int ld_in, int 
 // src[row*ld + k], or src[k*ld + row] when `transposed`).
 size_t tp_bytes(int rows, int K);
 void launch_tp_split(const float* src, unsigned char* tp, int rows, int K, int ld, bool transposed, hipStream_t st);
+// both forms in one pass over src [rows][K]: tpN = planes of src, tpT = planes of its transpose ([K rows][rows])
+void launch_tp_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, hipStream_t st);
 struct GemmTPDesc {
   const unsigned char* A;   // TP of [>= M rows][K_A], starting at the first row block used
   const unsigned char* B;   // TP of [>= N rows][K_B]

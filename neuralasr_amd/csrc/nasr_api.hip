@@ -128,6 +128,8 @@ struct nasr_ctx {
   uint32_t drop_seed = 4567u, drop_counter = 0;   // random_seed of networks/deepspeech.py:26
 
   float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *Uf = nullptr, *Ub = nullptr;
+  bool split2 = true;                        // NASR_SPLIT2=0: separate passes for the two plane sets of dG (A/B knob)
+  int gttp_layer = -1;                       // layer whose transposed dG planes gemm_dx has just written (fused split)
   float* Gbase = nullptr;                    // allocation behind G: [GRAD_HEAD floats, [0] = fault word][np_int gradients]
   // gradient buckets: (offset, count) in floats from Gbase, in the order backward() completes them; one event each
   std::vector<std::pair<int64_t, int64_t>> buckets;
@@ -722,12 +724,18 @@ void gemm_xproj(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
 }
 
 // dOut_{l-1}[r0 ..) = dG_l[r0 ..) * Wx_l^T : the gradient wrt layer l's input = the layer below's output
-void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
+// with_transposed: the call covers all R rows and weight_grads(l) follows - dG is split once into both plane sets
+void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st, bool with_transposed = false) {
   const int D = h->D, N4 = h->N4, Hp = h->Hp;
   const float* A = dg_of(h, l) + (size_t)r0 * D * N4;
   float* C = l > 0 ? dout_of(h, l - 1) + (size_t)r0 * D * Hp : h->dYbuf[h->npre - 1].as<float>() + (size_t)r0 * h->Ip[0];
   if (h->gemm_tp) {
-    launch_tp_split(A, h->GTP.as<unsigned char>(), nr, D * N4, D * N4, false, st);
+    if (with_transposed && h->split2) {
+      launch_tp_split2(A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), nr, D * N4, D * N4, st);
+      h->gttp_layer = l;
+    } else {
+      launch_tp_split(A, h->GTP.as<unsigned char>(), nr, D * N4, D * N4, false, st);
+    }
     GemmTPDesc g{};
     g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
     g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = h->Ip[l];
@@ -771,7 +779,8 @@ int dense_backward(nasr_ctx* h, int i, const float* X, float* dX) {
   const int nkb = (R + 15) / 16;
   float* dZ = h->dYbuf[i].as<float>();
   launch_dense_act_bwd(dZ, h->Ybuf[i].as<float>(), (int64_t)R * Wp, h->cfg.relu_clip, h->cfg.dropout[i], h->st);
-  launch_tp_split(dZ, h->GTTP.as<unsigned char>(), Wp, R, Wp, true, h->st);
+  if (dX && h->split2) launch_tp_split2(dZ, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), R, Wp, Wp, h->st);   // both forms of dZ at once
+  else launch_tp_split(dZ, h->GTTP.as<unsigned char>(), Wp, R, Wp, true, h->st);
   launch_tp_split(X, h->DTP.as<unsigned char>(), Ip, R, Ip, true, h->st);
   {  // dW = X^T dZ
     GemmTPDesc g{};
@@ -784,7 +793,7 @@ int dense_backward(nasr_ctx* h, int i, const float* X, float* dX) {
   }
   launch_colsum(dZ, R, Wp, Wp, h->G + h->off_db[i], h->csws.as<float>(), h->st);
   if (dX) {  // dX = dZ W^T
-    launch_tp_split(dZ, h->GTP.as<unsigned char>(), R, Wp, Wp, false, h->st);
+    if (!h->split2) launch_tp_split(dZ, h->GTP.as<unsigned char>(), R, Wp, Wp, false, h->st);
     GemmTPDesc g{};
     g.A = h->GTP.as<unsigned char>(); g.B = h->DbTP + h->off_dbtp[i]; g.C = dX;
     g.M = R; g.N = Ip; g.K = Wp; g.nkbA = (Wp + 15) / 16; g.nkbB = g.nkbA; g.ldc = Ip;
@@ -910,7 +919,8 @@ int weight_grads(nasr_ctx* h, int l) {
     unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
     unsigned char* GT = h->GTTP.as<unsigned char>();
     const int nkb = (R + 15) / 16;
-    launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);
+    if (h->gttp_layer != l) launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);   // else: made by gemm_dx's fused split
+    h->gttp_layer = -1;
     if (l == h->L - 1) launch_tp_split(h->outb[l].as<float>(), tO[l & 1], D * Hp, R, D * Hp, true, ws);
     if (l > 0) launch_tp_split(h->outb[l - 1].as<float>(), tO[(l - 1) & 1], D * Hp, R, D * Hp, true, ws);
     if (l == 0 && h->npre) launch_tp_split(Xl, h->X0TTP.as<unsigned char>(), h->Ip[0], R, h->Ip[0], true, ws);
@@ -1053,7 +1063,7 @@ int backward(nasr_ctx* h) {
         h->n_bwd_launch += h->persist ? 1 : T;
       }
       PhaseScope ps(h, PH_WGRAD);
-      if (l > 0 || h->npre > 0) gemm_dx(h, l, 0, R, h->st);   // critical path first
+      if (l > 0 || h->npre > 0) gemm_dx(h, l, 0, R, h->st, true);   // critical path first
       int rc = weight_grads(h, l);
       if (rc) return rc;
       if (h->bucket_of_layer[l] >= 0) HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
@@ -1196,6 +1206,8 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   {
     const char* e = getenv("NASR_GEMM");
     h->gemm_bf16 = !(e && std::string(e) == "f32");
+    const char* e2 = getenv("NASR_SPLIT2");
+    h->split2 = !(e2 && e2[0] == '0');
     // the tiled-plane copies of activations are single scratch buffers: not for the multi-stream layer pipeline
     const char* ep = getenv("NASR_PIPE");
     const char* es = getenv("NASR_PERSIST");

@@ -124,6 +124,31 @@ int main() {
         printf("sweep  dWx 576x4096x8000 tile rows %d split %2d : %.3f ms\n", tm, split, best);
       }
   }
+  // fused split: both plane sets from one pass must equal the two separate passes, byte for byte (also on ragged sizes)
+  for (int rr : {R, 7993}) for (int kk : {4096, 1000}) {
+    unsigned char *N1, *N2, *T1, *T2;
+    const size_t bn = tp_bytes(rr, kk), bt = tp_bytes(kk, rr);
+    CK(hipMalloc(&N1, bn)); CK(hipMalloc(&N2, bn)); CK(hipMalloc(&T1, bt)); CK(hipMalloc(&T2, bt));
+    CK(hipMemset(N2, 0xee, bn)); CK(hipMemset(T2, 0xee, bt));
+    launch_tp_split(G, N1, rr, kk, 4096, false, st); launch_tp_split(G, T1, kk, rr, 4096, true, st);
+    launch_tp_split2(G, N2, T2, rr, kk, 4096, st);
+    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+    std::vector<unsigned char> a1(bn), a2(bn), b1(bt), b2(bt);
+    CK(hipMemcpy(a1.data(), N1, bn, hipMemcpyDeviceToHost)); CK(hipMemcpy(a2.data(), N2, bn, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b1.data(), T1, bt, hipMemcpyDeviceToHost)); CK(hipMemcpy(b2.data(), T2, bt, hipMemcpyDeviceToHost));
+    size_t badn = 0, badt = 0;
+    for (size_t i = 0; i < bn; ++i) badn += a1[i] != a2[i];
+    for (size_t i = 0; i < bt; ++i) badt += b1[i] != b2[i];
+    float t1 = 1e9f, t2 = 1e9f;
+    for (int i = 0; i < 5; ++i) {
+      CK(hipEventRecord(a, st)); launch_tp_split(G, N1, rr, kk, 4096, false, st); launch_tp_split(G, T1, kk, rr, 4096, true, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); t1 = ms < t1 ? ms : t1;
+      CK(hipEventRecord(a, st)); launch_tp_split2(G, N2, T2, rr, kk, 4096, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&ms, a, b)); t2 = ms < t2 ? ms : t2;
+    }
+    printf("fused split %dx%d: %zu / %zu differing bytes (normal / transposed planes); two passes %.3f ms, one pass %.3f ms\n", rr, kk, badn, badt, t1, t2);
+    CK(hipFree(N1)); CK(hipFree(N2)); CK(hipFree(T1)); CK(hipFree(T2));
+  }
   // transposed split: TP from a [K][rows] source must equal TP from the explicit transpose
   {
     launch_transpose(G, O2, R, 4096, 4096, R, st);                 // O2 = G^T [4096][R]
