@@ -875,7 +875,11 @@ int forward(nasr_ctx* h) {
     g.lda = sr ? Hp : h->Pinp; g.ldb = h->Cp; g.ldc = h->Cp;
     g.a_map = sr ? h->rowmap.as<int>() : nullptr;
     g.a_rows = sr ? 2 * R : R;
-    g.bias = h->P + h->off_b; g.split_k = 1;
+    g.bias = h->P + h->off_b;
+    // N = Cp (32 for the 29 classes) gives the 128-row tiles of gemm.hip one block column: split K to fill the chip
+    g.split_k = gemm_pick_split(g.M, g.N, g.K);
+    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+    if (g.split_k > 1 && !g.slabs) g.split_k = 1;
     launch_gemm(g, h->st);
     HIPCHK(h, hipGetLastError());
   }
