@@ -110,8 +110,11 @@ __global__ __launch_bounds__(256) void tp_split_kernel(const float* __restrict__
 // column) and tpT = planes of its transpose (row = src column, k = src row) - dG feeds the input-gradient GEMM in the
 // first form and the weight-gradient GEMMs in the second.  A block stages a 64 x 64 fp32 piece in LDS; grid
 // (ceil(K/64), ceil(rows/64)), 256 threads.
+// tpN may be NULL (transposed planes only).  colpart (or NULL): [gridDim.y][K] partial column sums of src, 64 rows
+// each, summed afterwards by launch_colsum_parts - the bias gradient rides on the pass that reads dG anyway.
 __global__ __launch_bounds__(256) void tp_split2_kernel(const float* __restrict__ src, unsigned char* __restrict__ tpN,
-                                                        unsigned char* __restrict__ tpT, int rows, int K, int ld) {
+                                                        unsigned char* __restrict__ tpT, int rows, int K, int ld,
+                                                        float* __restrict__ colpart) {
   __shared__ float tile[64][65];
   const int t = threadIdx.x;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -133,6 +136,16 @@ __global__ __launch_bounds__(256) void tp_split2_kernel(const float* __restrict_
     tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
   }
   __syncthreads();
+  __shared__ float csum[4][64];
+  if (colpart) {
+    const int j = t & 63, q = t >> 6;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += tile[16 * q + r][j];
+    csum[q][j] = sum;
+    __syncthreads();
+    if (q == 0 && c0 + j < K) colpart[(size_t)blockIdx.y * K + c0 + j] = (csum[0][j] + csum[1][j]) + (csum[2][j] + csum[3][j]);
+  }
   auto emit = [&](const float (&x)[8], unsigned char* dst) {
     bf16x8 p1, p2, p3;
 #pragma unroll
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256) void tp_split2_kernel(const float* __restrict_
   for (int i = 0; i < 2; ++i) {
     const int g = t + 256 * i;                    // granule 0..511
     float x[8];
-    {  // planes of src: granule = (row g >> 3, columns 8 (g & 7) ..)
+    if (tpN) {  // planes of src: granule = (row g >> 3, columns 8 (g & 7) ..)
       const int r = g >> 3, c = g & 7;
       const int row = r0 + r, kb = (c0 >> 4) + (c >> 1);
 #pragma unroll
@@ -170,9 +183,12 @@ __global__ __launch_bounds__(256) void tp_split2_kernel(const float* __restrict_
   }
 }
 
-void launch_tp_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, hipStream_t st) {
+int tp_split2_parts(int rows) { return (rows + 63) / 64; }
+
+void launch_tp_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, float* colpart,
+                      hipStream_t st) {
   dim3 grid((K + 63) / 64, (rows + 63) / 64);
-  hipLaunchKernelGGL(tp_split2_kernel, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld);
+  hipLaunchKernelGGL(tp_split2_kernel, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld, colpart);
 }
 
 size_t tp_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 3 * TPB; }

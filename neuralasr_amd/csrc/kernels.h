@@ -52,8 +52,11 @@ void launch_transpose(const float* in, float* out, int R, int C, int ld_in, int 
 // src[row*ld + k], or src[k*ld + row] when `transposed`).
 size_t tp_bytes(int rows, int K);
 void launch_tp_split(const float* src, unsigned char* tp, int rows, int K, int ld, bool transposed, hipStream_t st);
-// both forms in one pass over src [rows][K]: tpN = planes of src, tpT = planes of its transpose ([K rows][rows])
-void launch_tp_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, hipStream_t st);
+// both forms in one pass over src [rows][K]: tpN = planes of src (or NULL), tpT = planes of its transpose ([K rows][rows]);
+// colpart (or NULL): tp_split2_parts(rows) x K partial column sums of src, finished by launch_colsum_parts
+int tp_split2_parts(int rows);
+void launch_tp_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, float* colpart,
+                      hipStream_t st);
 struct GemmTPDesc {
   const unsigned char* A;   // TP of [>= M rows][K_A], starting at the first row block used
   const unsigned char* B;   // TP of [>= N rows][K_B]
@@ -141,6 +144,7 @@ void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float 
                  float eps, float gscale, const float* fault, hipStream_t st);
 // out[n] = sum_r M[r*ld + n], deterministic two-stage; ws holds 32*N floats
 void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st);
+void launch_colsum_parts(const float* part, int nparts, int N, float* out, hipStream_t st);   // out[n] = sum_k part[k][n]
 void launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, hipStream_t st);
 
 }  // namespace nasr

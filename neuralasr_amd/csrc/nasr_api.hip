@@ -489,7 +489,8 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->rowmap.ensure((size_t)Tp * Bp * 4, &grew);
   int csw = std::max(D * N4, h->Cp);
   for (int i = 0; i < h->ndense; ++i) csw = std::max(csw, h->dWp[i]);
-  ok &= h->csws.ensure((size_t)32 * csw * 4, &grew);
+  // column-sum partials: 32 rows of launch_colsum, or the 64-row partials of the fused split pass (tp_split2_parts)
+  ok &= h->csws.ensure((size_t)std::max(32, h->gemm_tp ? tp_split2_parts((int)R) : 0) * csw * 4, &grew);
   ok &= h->amax.ensure((size_t)Tp * Bp * 4, &grew);
   ok &= h->ids.ensure((size_t)B * Tp * 4, &grew);
   ok &= h->lens.ensure((size_t)Bp * 4, &grew);
@@ -731,8 +732,9 @@ void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st, bool with_trans
   float* C = l > 0 ? dout_of(h, l - 1) + (size_t)r0 * D * Hp : h->dYbuf[h->npre - 1].as<float>() + (size_t)r0 * h->Ip[0];
   if (h->gemm_tp) {
     if (with_transposed && h->split2) {
-      launch_tp_split2(A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), nr, D * N4, D * N4, st);
-      h->gttp_layer = l;
+      launch_tp_split2(A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), nr, D * N4, D * N4,
+                       h->csws.as<float>(), st);
+      h->gttp_layer = l;   // weight_grads(l): transposed planes and column-sum partials of dG are there
     } else {
       launch_tp_split(A, h->GTP.as<unsigned char>(), nr, D * N4, D * N4, false, st);
     }
@@ -779,7 +781,9 @@ int dense_backward(nasr_ctx* h, int i, const float* X, float* dX) {
   const int nkb = (R + 15) / 16;
   float* dZ = h->dYbuf[i].as<float>();
   launch_dense_act_bwd(dZ, h->Ybuf[i].as<float>(), (int64_t)R * Wp, h->cfg.relu_clip, h->cfg.dropout[i], h->st);
-  if (dX && h->split2) launch_tp_split2(dZ, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), R, Wp, Wp, h->st);   // both forms of dZ at once
+  if (h->split2)   // both forms of dZ (the first only when an input gradient follows) + column-sum partials in one pass
+    launch_tp_split2(dZ, dX ? h->GTP.as<unsigned char>() : nullptr, h->GTTP.as<unsigned char>(), R, Wp, Wp,
+                     h->csws.as<float>(), h->st);
   else launch_tp_split(dZ, h->GTTP.as<unsigned char>(), Wp, R, Wp, true, h->st);
   launch_tp_split(X, h->DTP.as<unsigned char>(), Ip, R, Ip, true, h->st);
   {  // dW = X^T dZ
@@ -791,7 +795,8 @@ int dense_backward(nasr_ctx* h, int i, const float* X, float* dX) {
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
     launch_gemm_tp(g, h->st);
   }
-  launch_colsum(dZ, R, Wp, Wp, h->G + h->off_db[i], h->csws.as<float>(), h->st);
+  if (h->split2) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), Wp, h->G + h->off_db[i], h->st);
+  else launch_colsum(dZ, R, Wp, Wp, h->G + h->off_db[i], h->csws.as<float>(), h->st);
   if (dX) {  // dX = dZ W^T
     if (!h->split2) launch_tp_split(dZ, h->GTP.as<unsigned char>(), R, Wp, Wp, false, h->st);
     GemmTPDesc g{};
@@ -923,7 +928,11 @@ int weight_grads(nasr_ctx* h, int l) {
     unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
     unsigned char* GT = h->GTTP.as<unsigned char>();
     const int nkb = (R + 15) / 16;
-    if (h->gttp_layer != l) launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);   // else: made by gemm_dx's fused split
+    // one pass over dG: its transposed planes + 16-row partial column sums (and, in gemm_dx, its own planes)
+    if (h->gttp_layer != l) {
+      if (h->split2) launch_tp_split2(dG, nullptr, GT, R, D * N4, D * N4, h->csws.as<float>(), ws);
+      else launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);
+    }
     h->gttp_layer = -1;
     if (l == h->L - 1) launch_tp_split(h->outb[l].as<float>(), tO[l & 1], D * Hp, R, D * Hp, true, ws);
     if (l > 0) launch_tp_split(h->outb[l - 1].as<float>(), tO[(l - 1) & 1], D * Hp, R, D * Hp, true, ws);
@@ -938,7 +947,8 @@ int weight_grads(nasr_ctx* h, int l) {
       if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
       launch_gemm_tp(g, ws);
     }
-    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
+    if (h->split2) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
+    else launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
     for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
       GemmTPDesc g{};
       g.A = tO[l & 1] + (size_t)(d * Hp / 32) * nkb * 3 * 1024;

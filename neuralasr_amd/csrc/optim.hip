@@ -63,18 +63,27 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   if (ry == 0 && n < N) part[(size_t)rs * N + n] = (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]);
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int N,
+// fixed-order sum of `nparts` partial rows; 4 threads per column (k = q, q+4, ...) combined through LDS
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int N,
                                                            float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int k = 0; k < CS_SPLIT; ++k) s += part[(size_t)k * N + n];
-  out[n] = s;
+  if (n < N)
+    for (int k = q; k < nparts; k += 4) s += part[(size_t)k * N + n];
+  sm[q][cx] = s;
+  __syncthreads();
+  if (q == 0 && n < N) out[n] = (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]);
+}
+
+void launch_colsum_parts(const float* part, int nparts, int N, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, st, part, nparts, N, out);
 }
 
 void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st) {
   hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, CS_SPLIT), dim3(256), 0, st, M, R, N, ld, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, N, out);
+  launch_colsum_parts(ws, CS_SPLIT, N, out, st);
 }
 
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int S, int64_t n,

@@ -131,7 +131,7 @@ int main() {
     CK(hipMalloc(&N1, bn)); CK(hipMalloc(&N2, bn)); CK(hipMalloc(&T1, bt)); CK(hipMalloc(&T2, bt));
     CK(hipMemset(N2, 0xee, bn)); CK(hipMemset(T2, 0xee, bt));
     launch_tp_split(G, N1, rr, kk, 4096, false, st); launch_tp_split(G, T1, kk, rr, 4096, true, st);
-    launch_tp_split2(G, N2, T2, rr, kk, 4096, st);
+    launch_tp_split2(G, N2, T2, rr, kk, 4096, nullptr, st);
     CK(hipStreamSynchronize(st)); CK(hipGetLastError());
     std::vector<unsigned char> a1(bn), a2(bn), b1(bt), b2(bt);
     CK(hipMemcpy(a1.data(), N1, bn, hipMemcpyDeviceToHost)); CK(hipMemcpy(a2.data(), N2, bn, hipMemcpyDeviceToHost));
@@ -143,11 +143,37 @@ int main() {
     for (int i = 0; i < 5; ++i) {
       CK(hipEventRecord(a, st)); launch_tp_split(G, N1, rr, kk, 4096, false, st); launch_tp_split(G, T1, kk, rr, 4096, true, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b)); t1 = ms < t1 ? ms : t1;
-      CK(hipEventRecord(a, st)); launch_tp_split2(G, N2, T2, rr, kk, 4096, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      CK(hipEventRecord(a, st)); launch_tp_split2(G, N2, T2, rr, kk, 4096, nullptr, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
       CK(hipEventElapsedTime(&ms, a, b)); t2 = ms < t2 ? ms : t2;
     }
     printf("fused split %dx%d: %zu / %zu differing bytes (normal / transposed planes); two passes %.3f ms, one pass %.3f ms\n", rr, kk, badn, badt, t1, t2);
     CK(hipFree(N1)); CK(hipFree(N2)); CK(hipFree(T1)); CK(hipFree(T2));
+  }
+  {  // the fused pass and its options on dG [8000][4096]
+    unsigned char *N2, *T2; float* cp;
+    CK(hipMalloc(&N2, tp_bytes(R, 4096))); CK(hipMalloc(&T2, tp_bytes(4096, R))); CK(hipMalloc(&cp, (size_t)tp_split2_parts(R) * 4096 * 4));
+    struct V { const char* name; bool n, c; } vs[] = {{"both planes", true, false}, {"both planes + column sums", true, true},
+                                                      {"transposed only", false, false}, {"transposed only + column sums", false, true}};
+    for (auto& v : vs) {
+      float best = 1e9f;
+      for (int i = 0; i < 6; ++i) {
+        CK(hipEventRecord(a, st)); launch_tp_split2(G, v.n ? N2 : nullptr, T2, R, 4096, 4096, v.c ? cp : nullptr, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+      }
+      printf("fused pass, %s: %.3f ms\n", v.name, best);
+    }
+    float best = 1e9f;
+    for (int i = 0; i < 6; ++i) {
+      CK(hipEventRecord(a, st)); launch_colsum(G, R, 4096, 4096, O2, cp, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+    }
+    printf("separate column-sum pass: %.3f ms\n", best);
+    best = 1e9f;
+    for (int i = 0; i < 6; ++i) {
+      CK(hipEventRecord(a, st)); launch_colsum_parts(cp, tp_split2_parts(R), 4096, O2, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+    }
+    printf("sum of the fused pass's %d partial rows: %.3f ms\n", tp_split2_parts(R), best);
   }
   // transposed split: TP from a [K][rows] source must equal TP from the explicit transpose
   {
