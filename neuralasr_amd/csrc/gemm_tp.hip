@@ -55,6 +55,11 @@ struct GemmTPParams {
   const float* bias;
   int split_k, kb_chunk;
   float* slabs;
+  // two products in one launch (blockIdx.z = slice * nbatch + batch): batch 1 reads A / B this many bytes further on,
+  // writes C c_bstride floats further on and uses its own k-block shift
+  int nbatch;
+  long long a_bstride, b_bstride, c_bstride;
+  int a_kb_shift1;
 };
 
 }  // namespace
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 256;
-  const int kb0 = blockIdx.z * p.kb_chunk;
+  const int bz = p.nbatch > 1 ? (int)(blockIdx.z % p.nbatch) : 0, zs = p.nbatch > 1 ? (int)(blockIdx.z / p.nbatch) : (int)blockIdx.z;
+  const int kb0 = zs * p.kb_chunk;
   const int kb1 = min(p.kbs, kb0 + p.kb_chunk);
   const int wm = w >> 2, wn = w & 3;
 
@@ -231,8 +237,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
     const int rb = ((isB ? n0 : m0) >> 5) + rbl;
     const int nkb = isB ? p.nkbB : p.nkbA;
     const bool ok = rb * 32 < (isB ? p.N : p.M);
-    tbase[i] = ok ? (uint64_t)(isB ? p.B : p.A) + ((size_t)rb * nkb * 3 + part) * TPB : 0;
-    tshift[i] = isB ? 0 : p.a_kb_shift;
+    tbase[i] = ok ? (uint64_t)(isB ? p.B : p.A) + (uint64_t)(bz ? (isB ? p.b_bstride : p.a_bstride) : 0) +
+                        ((size_t)rb * nkb * 3 + part) * TPB : 0;
+    tshift[i] = isB ? 0 : (bz ? p.a_kb_shift1 : p.a_kb_shift);
     tnkb[i] = ok ? nkb : 0;                     // 0: every k-block reads as zero
   }
   auto issue = [&](int kb, int buf) {
@@ -343,8 +350,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tp_kernel(GemmTPParams p) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (32 * TMW) + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= p.M) continue;
-        if (p.split_k > 1) p.slabs[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[mi][ni][r];
-        else p.C[(size_t)row * p.ldc + col] = acc[mi][ni][r] + bv;
+        if (p.split_k > 1) p.slabs[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[mi][ni][r];   // [slice][batch][M][N]
+        else p.C[(size_t)bz * p.c_bstride + (size_t)row * p.ldc + col] = acc[mi][ni][r] + bv;
       }
     }
 }
@@ -367,12 +374,12 @@ int gemm_tp_tile_rows(int M) {
 // K split by a cost model in units of one k-step of one block (measured 2.6 us for the 256-row tile whether one or two
 // blocks share a CU: they share its MFMA pipes): blocks run in rounds of 256 (one per CU), every slice keeps >= 16
 // k-steps, and each slab costs a write + a read of M x N floats at ~4 TB/s.
-int gemm_tp_pick_split(int M, int N, int K) {
+int gemm_tp_pick_split(int M, int N, int K, int nbatch) {
   const int tm = gemm_tp_tile_rows(M);
-  const int tiles = ((M + tm - 1) / tm) * ((N + 255) / 256);
+  const int tiles = ((M + tm - 1) / tm) * ((N + 255) / 256) * (nbatch > 1 ? 2 : 1);
   const int kbs = (K + 15) / 16;
   const double kstep = 2.6e-6 * tm / 256.0;
-  const double slab = (double)M * N * 8.0 / 4e12 / kstep;
+  const double slab = (double)(nbatch > 1 ? 2 : 1) * M * N * 8.0 / 4e12 / kstep;
   int best = 1;
   double best_cost = 1e30;
   for (int s = 1; s <= 64; ++s) {
@@ -397,10 +404,14 @@ void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st) {
   p.split_k = (p.kbs + per - 1) / per;
   p.slabs = g.slabs;
   const int tm = g.tile_rows ? g.tile_rows : gemm_tp_tile_rows(g.M);
-  dim3 grid((g.N + 255) / 256, (g.M + tm - 1) / tm, p.split_k);
+  p.nbatch = g.nbatch > 1 ? 2 : 1;
+  p.a_bstride = (long long)g.a_bstride; p.b_bstride = (long long)g.b_bstride; p.c_bstride = (long long)g.c_bstride;
+  p.a_kb_shift1 = g.a_kshift1 / 16;
+  dim3 grid((g.N + 255) / 256, (g.M + tm - 1) / tm, p.split_k * p.nbatch);
   if (tm == 192) hipLaunchKernelGGL(gemm_tp_kernel<3>, grid, dim3(512), GEMM_TP_LDS, st, p);
   else hipLaunchKernelGGL(gemm_tp_kernel<4>, grid, dim3(512), GEMM_TP_LDS, st, p);
-  if (p.split_k > 1) launch_reduce_slabs(g.slabs, p.split_k, (int64_t)g.M * g.N, g.C, st);   // needs ldc == N, no bias
+  // needs ldc == N, no bias; two batches: c_bstride == M * N (their results are adjacent, one reduction covers both)
+  if (p.split_k > 1) launch_reduce_slabs(g.slabs, p.split_k, (int64_t)p.nbatch * g.M * g.N, g.C, st);
 }
 
 }  // namespace nasr

@@ -69,10 +69,17 @@ struct GemmTPDesc {
   int split_k;              // > 1: partial slabs + reduction; needs ldc == N and no bias
   float* slabs;             // split_k * M * N floats
   int tile_rows;            // 0: gemm_tp_tile_rows(M); 192 / 256 forces the block tile (tools/gemmbench.hip)
+  // nbatch == 2: a second product of the same shape in the same launch (the two directions' recurrent weight gradients):
+  // its operands start a_bstride / b_bstride BYTES after A / B, its result c_bstride floats after C, its A shift is
+  // a_kshift1.  With split_k > 1: c_bstride must be M * N (one reduction covers both) and slabs hold 2 * split_k * M * N.
+  int nbatch;
+  size_t a_bstride, b_bstride;
+  int64_t c_bstride;
+  int a_kshift1;
 };
 hipError_t gemm_tp_prepare();    // once per process: raise the kernel's dynamic-LDS limit
 int gemm_tp_tile_rows(int M);
-int gemm_tp_pick_split(int M, int N, int K);
+int gemm_tp_pick_split(int M, int N, int K, int nbatch = 1);
 void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st);
 
 // ---- LSTM recurrence (lstm.hip) ----

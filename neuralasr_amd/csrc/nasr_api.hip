@@ -949,15 +949,17 @@ int weight_grads(nasr_ctx* h, int l) {
     }
     if (h->split2) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
     else launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
-    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
+    {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw); both directions in one launch
       GemmTPDesc g{};
-      g.A = tO[l & 1] + (size_t)(d * Hp / 32) * nkb * 3 * 1024;
-      g.B = GT + (size_t)(d * N4 / 32) * nkb * 3 * 1024;
-      g.C = h->G + h->off_u[(size_t)l * D + d];
+      g.A = tO[l & 1]; g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
       g.M = Hp; g.N = N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
-      g.a_kshift = d == 0 ? -Bp : Bp;
-      g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+      g.a_kshift = -Bp;
+      g.nbatch = D;
+      g.a_bstride = (size_t)(Hp / 32) * nkb * 3 * 1024; g.b_bstride = (size_t)(N4 / 32) * nkb * 3 * 1024;
+      g.c_bstride = (int64_t)Hp * N4;            // off_u[l*D + 1] - off_u[l*D] (build_layout)
+      g.a_kshift1 = Bp;
+      g.split_k = gemm_tp_pick_split(g.M, g.N, g.K, D);
+      g.slabs = ensure_slabs(h, g.split_k * D, g.M, g.N);
       if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
       launch_gemm_tp(g, ws);
     }
