@@ -110,7 +110,9 @@ bool persist_supported(int Hp);
 size_t persist_image_floats(int Hp, bool bwd);   // floats of one direction's operand image
 size_t persist_xch_floats(int Hp);               // floats of the exchange buffer (shared by forward and BPTT)
 hipError_t persist_prepare();                    // once per process: raise the kernels' dynamic-LDS limit
-void launch_repack_persist(const float* U, float* Upf, float* Upb, int Hp, hipStream_t st);
+// all n (layer, direction) matrices in one launch: matrix k is P + offs[k], its images Upf + k*image_floats(fwd) / Upb + k*...(bwd)
+constexpr int PERSIST_MAX_MATS = 16;
+void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Upf, float* Upb, int Hp, hipStream_t st);
 // Upf/Upb: [D] images of this layer; xch: persist_xch_floats(Hp) floats; ctl: one PersistCtl (zeroed by the launcher);
 // sticky: host-mapped word that receives the error code of an aborted launch (or NULL); fault: device float set to 1
 // by an aborted launch (or NULL) - the engine keeps it behind the gradients so that it is all-reduced with them

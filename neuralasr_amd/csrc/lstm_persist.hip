@@ -133,8 +133,14 @@ __device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, fl
 //        output column of unit NU*m + b', gate g (zero for b' >= NU).
 //   Upb [32 m][4 w][NOG*4NU idx][64 lane]: idx = og*4NU + c contracts gate column 4*NU*m + c; lane = 4*b' + jc is
 //        the output unit k = w*KW + og*64 + lane (zero when og*64 + lane >= KW).
-__global__ __launch_bounds__(256) void repack_persist_kernel(const float* __restrict__ U, float* __restrict__ Upf,
-                                                             float* __restrict__ Upb, int Hp) {
+// blockIdx.y = (layer, direction) k: its matrix starts at P + off.o[k], its images at Upf0 + k*imf / Upb0 + k*imb
+struct RepackOffs { long long o[PERSIST_MAX_MATS]; };
+__global__ __launch_bounds__(256) void repack_persist_kernel(const float* __restrict__ P, RepackOffs off,
+                                                             float* __restrict__ Upf0, float* __restrict__ Upb0,
+                                                             long long imf, long long imb, int Hp) {
+  const float* __restrict__ U = P + off.o[blockIdx.y];
+  float* __restrict__ Upf = Upf0 + (size_t)blockIdx.y * imf;
+  float* __restrict__ Upb = Upb0 + (size_t)blockIdx.y * imb;
   const int NU = Hp / 32, KW = 8 * NU, N4 = 4 * Hp;
   const int NOG = (KW + 63) / 64, KB = NOG * 4 * NU;
   const int64_t nf = (int64_t)32 * 4 * KW * 64, nb = (int64_t)32 * 4 * KB * 64;
@@ -164,8 +170,15 @@ size_t persist_image_floats(int Hp, bool bwd) {
   return (size_t)32 * 4 * 64 * (bwd ? NOG * 4 * NU : KW);
 }
 
-void launch_repack_persist(const float* U, float* Upf, float* Upb, int Hp, hipStream_t st) {
-  hipLaunchKernelGGL(repack_persist_kernel, dim3(1024), dim3(256), 0, st, U, Upf, Upb, Hp);
+void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Upf, float* Upb, int Hp, hipStream_t st) {
+  const long long imf = (long long)persist_image_floats(Hp, false), imb = (long long)persist_image_floats(Hp, true);
+  for (int k0 = 0; k0 < n; k0 += PERSIST_MAX_MATS) {
+    const int m = n - k0 < PERSIST_MAX_MATS ? n - k0 : PERSIST_MAX_MATS;
+    RepackOffs off{};
+    for (int k = 0; k < m; ++k) off.o[k] = offs[k0 + k];
+    hipLaunchKernelGGL(repack_persist_kernel, dim3(512, m), dim3(256), 0, st, P, off, Upf + (size_t)k0 * imf,
+                       Upb + (size_t)k0 * imb, imf, imb, Hp);
+  }
 }
 
 // ------------------------------------------------------------------ forward

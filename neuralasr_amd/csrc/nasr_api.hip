@@ -394,24 +394,32 @@ int build_layout(nasr_ctx* h) {
 }
 
 int repack(nasr_ctx* h) {
-  for (int l = 0; l < h->L; ++l)
-    for (int d = 0; d < h->D; ++d) {
-      const size_t k = (size_t)l * h->D + d;
-      const size_t o = k * (size_t)h->Hp * h->N4;
-      // only the operand images of the kernels in use (a mode switch calls repack again)
-      if (h->persist) launch_repack_persist(h->P + h->off_u[k], h->Upf + k * h->imf, h->Upb + k * h->imb, h->Hp, h->st);
-      else launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
-    }
+  // only the operand images of the kernels in use (a mode switch calls repack again)
+  if (h->persist) {
+    launch_repack_persist(h->P, h->off_u.data(), (int)h->off_u.size(), h->Upf, h->Upb, h->Hp, h->st);
+  } else {
+    for (int l = 0; l < h->L; ++l)
+      for (int d = 0; d < h->D; ++d) {
+        const size_t k = (size_t)l * h->D + d;
+        const size_t o = k * (size_t)h->Hp * h->N4;
+        launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
+      }
+  }
   if (h->gemm_tp) {
     for (int l = 0; l < h->L; ++l) {
-      launch_tp_split(h->P + h->off_wx[l], h->WfTP + h->off_wftp[l], h->D * h->N4, h->Ip[l], h->D * h->N4, true, h->st);
+      // forward operand = planes of Wx^T, input-gradient operand = planes of Wx: one pass where both are needed
       if (l > 0 || h->npre > 0)
-        launch_tp_split(h->P + h->off_wx[l], h->WbTP + h->off_wbtp[l], h->Ip[l], h->D * h->N4, h->D * h->N4, false, h->st);
+        launch_tp_split2(h->P + h->off_wx[l], h->WbTP + h->off_wbtp[l], h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
+                         h->D * h->N4, nullptr, h->st);
+      else
+        launch_tp_split(h->P + h->off_wx[l], h->WfTP + h->off_wftp[l], h->D * h->N4, h->Ip[l], h->D * h->N4, true, h->st);
     }
     for (int i = 0; i < h->ndense; ++i) {
-      launch_tp_split(h->P + h->off_dw[i], h->DfTP + h->off_dftp[i], h->dWp[i], h->dIp[i], h->dWp[i], true, h->st);
       if (i > 0 || h->npre == 0)   // the first pre stage reads the features: no gradient wrt its input
-        launch_tp_split(h->P + h->off_dw[i], h->DbTP + h->off_dbtp[i], h->dIp[i], h->dWp[i], h->dWp[i], false, h->st);
+        launch_tp_split2(h->P + h->off_dw[i], h->DbTP + h->off_dbtp[i], h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i],
+                         h->dWp[i], nullptr, h->st);
+      else
+        launch_tp_split(h->P + h->off_dw[i], h->DfTP + h->off_dftp[i], h->dWp[i], h->dIp[i], h->dWp[i], true, h->st);
     }
   } else if (h->gemm_bf16)
     for (int l = 0; l < h->L; ++l)

@@ -76,7 +76,10 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   for (int d = 0; d < D; ++d) {
     launch_repack_u(U + (size_t)d * Hp * N4, Uf + (size_t)d * Hp * N4, Ub + (size_t)d * Hp * N4, Hp, st);
-    launch_repack_persist(U + (size_t)d * Hp * N4, Upf + d * imf, Upb + d * imb, Hp, st);
+  }
+  {
+    int64_t offs[2] = {0, (int64_t)Hp * N4};
+    launch_repack_persist(U, offs, D, Upf, Upb, Hp, st);
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms;
