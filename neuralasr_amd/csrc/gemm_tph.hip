@@ -1,0 +1,383 @@
+// gemm_tph.hip — the tiled-plane GEMM of gemm_tp.hip on TWO fp16 parts per element and THREE MFMA products instead of
+// three bf16 parts and six products:
+//     C[M,N] = A[M,K] * B[N,K]^T (+bias[n])
+//
+// x*s = h1 + h2 with h1 = fp16(x*s), h2 = fp16(x*s - h1): the two 11-bit significands and the sign of h2 hold x*s to
+// 2^-24 relative - fp32's own rounding - PROVIDED neither part leaves fp16's exponent range.  That is what the scale s
+// is for: a power of two per row of the operand (constant along the contraction, so it factors out of the sum and the
+// epilogue multiplies by 1/(s_row * s_col), exactly) chosen so that the row's largest magnitude lands in [2^14, 2^15).
+// Elements down to 2^-18 of their row's maximum keep all 24 bits; below that the error is absolute, 2^-40 of the row
+// maximum (fp16 subnormal spacing 2^-24 against a maximum of 2^15) - far under what fp32 accumulation of the same dot
+// product loses.  x*y = h1*h1' + h1*h2' + h2*h1' + O(2^-24 xy), accumulated in fp32 by v_mfma_f32_32x32x16_f16: the same
+// accuracy class as the six bf16 products (bf16's 8-bit exponent needs no scale, its 8-bit significand three parts), at
+// half the matrix-core work and two thirds of the operand bytes.
+//
+// Layout: TPH[rb = row/32][kb = k/16][part 0..1][1 KiB tile], tiles swizzled as in gemm_tp.hip (tph_slot).  Kernel: 256
+// (or 192) x 256 output tile, TWO k-blocks per barrier (the 3-product chain is half as long: 48 MFMAs per wave and
+// barrier as before), two 64 KiB LDS buffers, 8 LDS-DMA instructions per wave and step.
+#include "kernels.h"
+
+namespace nasr {
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+constexpr int HTB = 1024;
+constexpr int TPH_LDS = 2 * 64 * HTB;
+
+__device__ __attribute__((aligned(1024))) unsigned char g_tph_zero[HTB];
+
+__device__ __forceinline__ int tph_slot(int r, int h) { return ((r << 1) | (h ^ ((r >> 3) & 1))) << 4; }
+
+struct GemmTPHParams {
+  const unsigned char* A;
+  const unsigned char* B;
+  float* C;
+  int M, N;
+  int nkbA, nkbB;
+  int kbs;
+  int ldc;
+  int a_kb_shift;
+  const float* bias;
+  const float* a_inv;      // [M] 1 / scale of A's rows
+  const float* b_inv;      // [N] 1 / scale of B's rows
+  int split_k, kb_chunk;
+  float* slabs;
+  int nbatch;
+  long long a_bstride, b_bstride, c_bstride, ainv_bstride, binv_bstride;
+  int a_kb_shift1;
+};
+
+__device__ __forceinline__ void emit_h2(const float (&x)[8], float s, unsigned char* dst) {
+  f16x8 p1, p2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = x[e] * s;                  // exact: s is a power of two
+    const _Float16 h1 = (_Float16)v;
+    p1[e] = h1;
+    p2[e] = (_Float16)(v - (float)h1);
+  }
+  *reinterpret_cast<f16x8*>(dst) = p1;
+  *reinterpret_cast<f16x8*>(dst + HTB) = p2;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ scales
+// max |src| per row and per column of src [rows][K]: 64 x 64 pieces, partial maxima [gridDim.x][rows] / [gridDim.y][K],
+// then one kernel turns maxima into (scale, 1/scale) = (2^(15-e), 2^(e-15)) with max < 2^e (frexp), 1 for an all-zero line.
+__global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ src, int rows, int K, int ld,
+                                                          float* __restrict__ rowpart, float* __restrict__ colpart) {
+  __shared__ float rm[64][5], cm[4][64];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int cq = t & 15, rq = t >> 4;          // thread: columns 4cq..4cq+3, rows rq, rq+16, rq+32, rq+48
+  float cmax[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rq + 16 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows) {
+      const float* s = src + (size_t)(r0 + r) * ld + c0 + 4 * cq;
+      if (c0 + 4 * cq + 4 <= K) v = *reinterpret_cast<const float4*>(s);
+      else {
+        if (c0 + 4 * cq < K) v.x = s[0];
+        if (c0 + 4 * cq + 1 < K) v.y = s[1];
+        if (c0 + 4 * cq + 2 < K) v.z = s[2];
+      }
+    }
+    v.x = fabsf(v.x); v.y = fabsf(v.y); v.z = fabsf(v.z); v.w = fabsf(v.w);
+    cmax[0] = fmaxf(cmax[0], v.x); cmax[1] = fmaxf(cmax[1], v.y); cmax[2] = fmaxf(cmax[2], v.z); cmax[3] = fmaxf(cmax[3], v.w);
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));   // row r, this thread's 4 columns: reduce over the 16 cq lanes
+    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+    if (cq == 0) rm[r][0] = m;
+  }
+  // columns: reduce over the 4 row groups of a wave (lanes 16 apart) then over the 4 waves through LDS
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float m = cmax[j];
+    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    if ((t & 63) < 16) cm[t >> 6][4 * cq + j] = m;
+  }
+  __syncthreads();
+  if (t < 64) {
+    if (rowpart && r0 + t < rows) rowpart[(size_t)blockIdx.x * rows + r0 + t] = rm[t][0];
+    if (colpart && c0 + t < K) colpart[(size_t)blockIdx.y * K + c0 + t] = fmaxf(fmaxf(cm[0][t], cm[1][t]), fmaxf(cm[2][t], cm[3][t]));
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_final_kernel(const float* __restrict__ part, int nparts, int n,
+                                                          float* __restrict__ scale, float* __restrict__ inv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = 0.f;
+  for (int k = 0; k < nparts; ++k) m = fmaxf(m, part[(size_t)k * n + i]);
+  int e = 0;
+  if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e); else e = 15;     // m = f * 2^e, f in [0.5, 1)
+  e = max(-100, min(100, e));
+  scale[i] = ldexpf(1.f, 15 - e);
+  inv[i] = ldexpf(1.f, e - 15);
+}
+
+size_t tph_scale_ws_floats(int rows, int K) { return (size_t)((K + 63) / 64) * rows + (size_t)((rows + 63) / 64) * K; }
+
+// row_scale / row_inv [rows], col_scale / col_inv [K] (either pair may be NULL); ws: tph_scale_ws_floats(rows, K)
+void launch_tph_scales(const float* src, int rows, int K, int ld, float* row_scale, float* row_inv, float* col_scale,
+                       float* col_inv, float* ws, hipStream_t st) {
+  dim3 grid((K + 63) / 64, (rows + 63) / 64);
+  float* rp = row_scale ? ws : nullptr;
+  float* cp = col_scale ? ws + (size_t)grid.x * rows : nullptr;
+  hipLaunchKernelGGL(absmax_part_kernel, grid, dim3(256), 0, st, src, rows, K, ld, rp, cp);
+  if (row_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, rp, (int)grid.x, rows, row_scale, row_inv);
+  if (col_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((K + 255) / 256), dim3(256), 0, st, cp, (int)grid.y, K, col_scale, col_inv);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill(float* p, float v, int n, hipStream_t st) {
+  hipLaunchKernelGGL(fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, v, n);
+}
+
+// ------------------------------------------------------------------ fp32 -> two fp16 planes
+// One pass over src [rows][K]: tpN = planes of src scaled per src row (row_scale, or the constant rs when NULL), tpT =
+// planes of its transpose scaled per src column (col_scale / cs); either may be NULL.  colpart as in gemm_tp.hip's fused
+// pass: [gridDim.y][K] partial column sums of the UNSCALED src.
+__global__ __launch_bounds__(256) void tph_split2_kernel(const float* __restrict__ src, unsigned char* __restrict__ tpN,
+                                                         unsigned char* __restrict__ tpT, int rows, int K, int ld,
+                                                         const float* __restrict__ row_scale, float rs,
+                                                         const float* __restrict__ col_scale, float cs,
+                                                         float* __restrict__ colpart) {
+  __shared__ float tile[64][65];
+  __shared__ float csum[4][64];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int nkbN = (K + 15) / 16, nrbN = (rows + 31) / 32;
+  const int nkbT = (rows + 15) / 16, nrbT = (K + 31) / 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows) {
+      const float* s = src + (size_t)(r0 + r) * ld + c0 + c;
+      if (c0 + c + 4 <= K) v = *reinterpret_cast<const float4*>(s);
+      else {
+        if (c0 + c < K) v.x = s[0];
+        if (c0 + c + 1 < K) v.y = s[1];
+        if (c0 + c + 2 < K) v.z = s[2];
+      }
+    }
+    tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+  }
+  __syncthreads();
+  if (colpart) {
+    const int j = t & 63, q = t >> 6;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += tile[16 * q + r][j];
+    csum[q][j] = sum;
+    __syncthreads();
+    if (q == 0 && c0 + j < K) colpart[(size_t)blockIdx.y * K + c0 + j] = (csum[0][j] + csum[1][j]) + (csum[2][j] + csum[3][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int g = t + 256 * i;
+    float x[8];
+    if (tpN) {
+      const int r = g >> 3, c = g & 7;
+      const int row = r0 + r, kb = (c0 >> 4) + (c >> 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = tile[r][8 * c + e];
+      if ((row >> 5) < nrbN && kb < nkbN) {
+        const float s = row_scale ? (row < rows ? row_scale[row] : 1.f) : rs;
+        emit_h2(x, s, tpN + ((size_t)(row >> 5) * nkbN + kb) * 2 * HTB + tph_slot(row & 31, c & 1));
+      }
+    }
+    if (tpT) {
+      const int j = g & 63, c = g >> 6;
+      const int row = c0 + j, kb = (r0 >> 4) + (c >> 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = tile[8 * c + e][j];
+      if ((row >> 5) < nrbT && kb < nkbT) {
+        const float s = col_scale ? (row < K ? col_scale[row] : 1.f) : cs;
+        emit_h2(x, s, tpT + ((size_t)(row >> 5) * nkbT + kb) * 2 * HTB + tph_slot(row & 31, c & 1));
+      }
+    }
+  }
+}
+
+size_t tph_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 2 * HTB; }
+
+void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
+                       const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st) {
+  dim3 grid((K + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(tph_split2_kernel, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld, row_scale, rs, col_scale, cs,
+                     colpart);
+}
+
+// ------------------------------------------------------------------ the GEMM
+template <int TMW>
+__global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  constexpr int TM = 64 * TMW;
+  constexpr int NA = TM / 32;                // A row blocks
+  constexpr int NRB = NA + 8;                // + B row blocks
+  constexpr int NT = NRB * 2 * 2;            // tiles per step: 2 k-blocks x row blocks x 2 parts
+  constexpr int NW = (NT + 7) / 8;           // DMA instructions per wave and step (8 or 7)
+  constexpr int BUFB = NT * HTB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 256;
+  const int bz = p.nbatch > 1 ? (int)(blockIdx.z % p.nbatch) : 0, zs = p.nbatch > 1 ? (int)(blockIdx.z / p.nbatch) : (int)blockIdx.z;
+  const int kb0 = zs * p.kb_chunk;                       // even
+  const int kb1 = min(p.kbs, kb0 + p.kb_chunk);
+  const int wm = w >> 2, wn = w & 3;
+
+  uint64_t zero = (uint64_t)g_tph_zero;
+  asm volatile("" : "+s"(zero));
+  // tile ti = ((kk * NRB + row block) * 2 + part); everything wave-uniform
+  uint64_t tbase[NW];
+  int tshift[NW], tnkb[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int ti = min(w * NW + i, NT - 1);
+    const int kk = ti / (NRB * 2), rem = ti - kk * (NRB * 2);
+    const int rbi = rem >> 1, part = rem & 1;
+    const bool isB = rbi >= NA;
+    const int rb = ((isB ? n0 : m0) >> 5) + (isB ? rbi - NA : rbi);
+    const int nkb = isB ? p.nkbB : p.nkbA;
+    const bool ok = rb * 32 < (isB ? p.N : p.M);
+    tbase[i] = ok ? (uint64_t)(isB ? p.B : p.A) + (uint64_t)(bz ? (isB ? p.b_bstride : p.a_bstride) : 0) +
+                        ((size_t)rb * nkb * 2 + part) * HTB : 0;
+    tshift[i] = kk + (isB ? 0 : (bz ? p.a_kb_shift1 : p.a_kb_shift));
+    tnkb[i] = ok ? nkb : 0;
+  }
+  auto issue = [&](int kb, int buf) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      if (w * NW + i >= NT) continue;
+      const int kk = kb + tshift[i];
+      const uint64_t g = ((unsigned)kk < (unsigned)tnkb[i]) ? tbase[i] + (uint64_t)kk * (2 * HTB) : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + lane * 16), (lds_ptr_t)(lds + buf * BUFB + (w * NW + i) * HTB), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TMW][2];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int foff = tph_slot(lane & 31, lane >> 5);
+  auto chain3 = [](f32x16 c, const f16x8 (&x)[2], const f16x8 (&y)[2]) {   // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[1], y[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], y[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[0], y[0], c, 0, 0, 0);
+    return c;
+  };
+
+  if (kb0 < kb1) issue(kb0, 0);
+  for (int kb = kb0; kb < kb1; kb += 2) {
+    const int buf = ((kb - kb0) >> 1) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kb + 2 < kb1) issue(kb + 2, buf ^ 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 a[TMW][2], b[2][2];
+      const unsigned char* base = lds + buf * BUFB + kk * (NRB * 2 * HTB) + foff;
+#pragma unroll
+      for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[i][q] = *reinterpret_cast<const f16x8*>(base + ((wm * TMW + i) * 2 + q) * HTB);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[j][q] = *reinterpret_cast<const f16x8*>(base + ((NA + wn * 2 + j) * 2 + q) * HTB);
+#pragma unroll
+      for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = chain3(acc[i][j], a[i], b[j]);
+    }
+  }
+
+  const int li = lane & 31, lh = lane >> 5;
+  const float* ainv = p.a_inv + (bz ? p.ainv_bstride : 0);
+  const float* binv = p.b_inv + (bz ? p.binv_bstride : 0);
+#pragma unroll
+  for (int mi = 0; mi < TMW; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + 32 * ni + li;
+      if (col >= p.N) continue;
+      const float bv = (p.bias && p.split_k == 1) ? p.bias[col] : 0.f;
+      const float sb = binv[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (32 * TMW) + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= p.M) continue;
+        const float v = acc[mi][ni][r] * (ainv[row] * sb);        // powers of two: exact
+        if (p.split_k > 1) p.slabs[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+        else p.C[(size_t)bz * p.c_bstride + (size_t)row * p.ldc + col] = v + bv;
+      }
+    }
+}
+
+hipError_t gemm_tph_prepare() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, TPH_LDS);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            TPH_LDS);
+  return e;
+}
+
+// same cost model as gemm_tp_pick_split with a k-step of half the duration; slices are even numbers of k-blocks
+int gemm_tph_pick_split(int M, int N, int K, int nbatch) {
+  const int tm = gemm_tp_tile_rows(M);
+  const int tiles = ((M + tm - 1) / tm) * ((N + 255) / 256) * (nbatch > 1 ? 2 : 1);
+  const int kbs = (K + 15) / 16;
+  const double kstep = 1.3e-6 * tm / 256.0;
+  const double slab = (double)(nbatch > 1 ? 2 : 1) * M * N * 8.0 / 4e12 / kstep;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 64; ++s) {
+    if (s > 1 && kbs / s < 32) break;
+    const int per = ((kbs + s - 1) / s + 1) & ~1;
+    const int rounds = (tiles * s + 255) / 256;
+    const double cost = (double)rounds * per + (s > 1 ? s * slab : 0.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
+void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st) {
+  GemmTPHParams p;
+  p.A = g.A; p.B = g.B; p.C = g.C; p.M = g.M; p.N = g.N;
+  p.nkbA = g.nkbA; p.nkbB = g.nkbB; p.kbs = (g.K + 15) / 16; p.ldc = g.ldc;
+  p.a_kb_shift = g.a_kshift / 16;
+  p.bias = g.bias; p.a_inv = g.a_inv; p.b_inv = g.b_inv;
+  int split = g.split_k < 1 ? 1 : g.split_k;
+  const int per = ((p.kbs + split - 1) / split + 1) & ~1;       // even: a step is two k-blocks
+  p.kb_chunk = per;
+  p.split_k = (p.kbs + per - 1) / per;
+  p.slabs = g.slabs;
+  const int tm = g.tile_rows ? g.tile_rows : gemm_tp_tile_rows(g.M);
+  p.nbatch = g.nbatch > 1 ? 2 : 1;
+  p.a_bstride = (long long)g.a_bstride; p.b_bstride = (long long)g.b_bstride; p.c_bstride = (long long)g.c_bstride;
+  p.ainv_bstride = (long long)g.ainv_bstride; p.binv_bstride = (long long)g.binv_bstride;
+  p.a_kb_shift1 = g.a_kshift1 / 16;
+  dim3 grid((g.N + 255) / 256, (g.M + tm - 1) / tm, p.split_k * p.nbatch);
+  if (tm == 192) hipLaunchKernelGGL(gemm_tph_kernel<3>, grid, dim3(512), TPH_LDS, st, p);
+  else hipLaunchKernelGGL(gemm_tph_kernel<4>, grid, dim3(512), TPH_LDS, st, p);
+  if (p.split_k > 1) launch_reduce_slabs(g.slabs, p.split_k, (int64_t)p.nbatch * g.M * g.N, g.C, st);
+}
+
+}  // namespace nasr

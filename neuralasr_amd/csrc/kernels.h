@@ -82,6 +82,41 @@ int gemm_tp_tile_rows(int M);
 int gemm_tp_pick_split(int M, int N, int K, int nbatch = 1);
 void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st);
 
+// ---- the same GEMM on two fp16 planes per element and three MFMA products (gemm_tph.hip) ----
+// Every operand row carries a power-of-two scale (constant along the contraction) that brings its largest magnitude into
+// [2^14, 2^15); the epilogue multiplies by the inverse scales of the output's row and column.
+size_t tph_bytes(int rows, int K);
+size_t tph_scale_ws_floats(int rows, int K);
+void launch_tph_scales(const float* src, int rows, int K, int ld, float* row_scale, float* row_inv, float* col_scale,
+                       float* col_inv, float* ws, hipStream_t st);
+void launch_fill(float* p, float v, int n, hipStream_t st);
+// one pass over src [rows][K]: tpN = planes of src (scale per src row: row_scale[] or the constant rs), tpT = planes of its
+// transpose (scale per src column: col_scale[] or cs); either may be NULL; colpart as in launch_tp_split2
+void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
+                       const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st);
+struct GemmTPHDesc {
+  const unsigned char* A;   // TPH of [>= M rows][K_A]
+  const unsigned char* B;   // TPH of [>= N rows][K_B]
+  float* C;
+  int M, N, K;
+  int nkbA, nkbB;
+  int ldc;
+  int a_kshift;
+  const float* bias;
+  const float* a_inv;       // [M] inverse scales of A's rows
+  const float* b_inv;       // [N] inverse scales of B's rows
+  int split_k;
+  float* slabs;
+  int tile_rows;
+  int nbatch;
+  size_t a_bstride, b_bstride;
+  int64_t c_bstride, ainv_bstride, binv_bstride;
+  int a_kshift1;
+};
+hipError_t gemm_tph_prepare();
+int gemm_tph_pick_split(int M, int N, int K, int nbatch = 1);
+void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st);
+
 // ---- LSTM recurrence (lstm.hip) ----
 struct LstmDims {
   int T, B, Bp, H, Hp, D;   // D directions

@@ -129,6 +129,25 @@ struct nasr_ctx {
 
   float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *Uf = nullptr, *Ub = nullptr;
   bool split2 = true;                        // NASR_SPLIT2=0: separate passes for the two plane sets of dG (A/B knob)
+  // Plane format of the tiled-plane GEMMs: three bf16 planes + six MFMA products (gemm_tp.hip; NASR_GEMM=tp3), or two
+  // fp16 planes + three products with a power-of-two scale per operand row (gemm_tph.hip; the default).  Scale vectors
+  // (device floats, scale and 1/scale): measured per step for everything whose range is not known in advance.
+  bool tph = false;
+  struct SV {
+    DevBuf s, inv;
+    bool ensure(size_t n) { bool g = false; return s.ensure(n * 4, &g) && inv.ensure(n * 4, &g); }
+    void release() { s.release(); inv.release(); }
+    float* sp() const { return s.as<float>(); }
+    float* ip() const { return inv.as<float>(); }
+  };
+  SV sc15;                                   // constants 2^15 / 2^-15: LSTM outputs (|h| < 1), rows and columns
+  size_t sc15_n = 0;
+  SV sc_x0r, sc_x0c;                         // features: per frame row / per feature column
+  std::vector<SV> sc_yr, sc_yc;              // dense stage outputs
+  SV sc_gr, sc_gc;                           // the gate / dense pre-activation gradient being worked on
+  std::vector<SV> sc_wr, sc_wc;              // Wx[l]: per input row / per gate column
+  std::vector<SV> sc_dr, sc_dc;              // dense W[i]
+  DevBuf scws;                               // partial maxima (launch_tph_scales)
   int gttp_layer = -1;                       // layer whose transposed dG planes gemm_dx has just written (fused split)
   float* Gbase = nullptr;                    // allocation behind G: [GRAD_HEAD floats, [0] = fault word][np_int gradients]
   // gradient buckets: (offset, count) in floats from Gbase, in the order backward() completes them; one event each
@@ -185,6 +204,57 @@ namespace {
 
 // A persistent launch that gave up (bounded spin, unexpected placement) leaves its outputs undefined: surface it at
 // the next host sync and use the per-step kernels from then on.
+// ---- tiled planes in either format ----------------------------------------------------------------------------
+inline size_t pl_rb_bytes(const nasr_ctx* h, int nkb) { return (size_t)nkb * (h->tph ? 2 : 3) * 1024; }   // one row block
+inline int pl_pick_split(const nasr_ctx* h, int M, int N, int K, int nbatch = 1) {
+  return h->tph ? gemm_tph_pick_split(M, N, K, nbatch) : gemm_tp_pick_split(M, N, K, nbatch);
+}
+// scales of src [rows][K]: per row into `row`, per column into `col` (either may be NULL); fp16 planes only
+void pl_scales(nasr_ctx* h, const float* src, int rows, int K, int ld, nasr_ctx::SV* row, nasr_ctx::SV* col, hipStream_t st) {
+  if (!h->tph) return;
+  launch_tph_scales(src, rows, K, ld, row ? row->sp() : nullptr, row ? row->ip() : nullptr, col ? col->sp() : nullptr,
+                    col ? col->ip() : nullptr, h->scws.as<float>(), st);
+}
+// planes of src [rows][K] (tpN, scaled per row by rs[]) and / or of its transpose (tpT, scaled per src column by cs[]);
+// colpart: partial column sums for launch_colsum_parts (bf16 planes: needs split2)
+void pl_split(nasr_ctx* h, const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
+              const float* rs, const float* cs, float* colpart, hipStream_t st) {
+  if (h->tph) {
+    launch_tph_split2(src, tpN, tpT, rows, K, ld, rs, 1.f, cs, 1.f, colpart, st);
+  } else if ((tpN && tpT) || colpart) {
+    launch_tp_split2(src, tpN, tpT, rows, K, ld, colpart, st);
+  } else if (tpN) {
+    launch_tp_split(src, tpN, rows, K, ld, false, st);
+  } else {
+    launch_tp_split(src, tpT, K, rows, ld, true, st);
+  }
+}
+// a_inv / b_inv: inverse scales of A's / B's rows (fp16 planes); the strides apply to batch 1 of a two-batch launch
+void pl_gemm(nasr_ctx* h, const GemmTPDesc& g, const float* a_inv, const float* b_inv, hipStream_t st,
+             int64_t ainv_bstride = 0, int64_t binv_bstride = 0) {
+  if (!h->tph) { launch_gemm_tp(g, st); return; }
+  GemmTPHDesc t{};
+  t.A = g.A; t.B = g.B; t.C = g.C; t.M = g.M; t.N = g.N; t.K = g.K; t.nkbA = g.nkbA; t.nkbB = g.nkbB; t.ldc = g.ldc;
+  t.a_kshift = g.a_kshift; t.bias = g.bias; t.a_inv = a_inv; t.b_inv = b_inv; t.split_k = g.split_k; t.slabs = g.slabs;
+  t.tile_rows = g.tile_rows; t.nbatch = g.nbatch; t.a_bstride = g.a_bstride; t.b_bstride = g.b_bstride;
+  t.c_bstride = g.c_bstride; t.ainv_bstride = ainv_bstride; t.binv_bstride = binv_bstride; t.a_kshift1 = g.a_kshift1;
+  launch_gemm_tph(t, st);
+}
+// scale vectors of an activation tensor: the features, a dense stage's output (index i), or an LSTM layer's output
+struct ActScale { const float *rs, *rinv, *cs, *cinv; };
+inline ActScale act_x0(const nasr_ctx* h) { return {h->sc_x0r.sp(), h->sc_x0r.ip(), h->sc_x0c.sp(), h->sc_x0c.ip()}; }
+inline ActScale act_y(const nasr_ctx* h, int i) { return {h->sc_yr[i].sp(), h->sc_yr[i].ip(), h->sc_yc[i].sp(), h->sc_yc[i].ip()}; }
+inline ActScale act_out(const nasr_ctx* h) { return {h->sc15.sp(), h->sc15.ip(), h->sc15.sp(), h->sc15.ip()}; }
+inline ActScale lstm_in_scale(const nasr_ctx* h, int l) {
+  if (l > 0) return act_out(h);
+  return h->npre ? act_y(h, h->npre - 1) : act_x0(h);
+}
+inline ActScale dense_in_scale(const nasr_ctx* h, int i) {
+  if (i == 0 && h->npre > 0) return act_x0(h);
+  if (i < h->npre) return act_y(h, i - 1);
+  return act_out(h);                               // the post stage reads the top LSTM layer
+}
+
 int repack(nasr_ctx* h);
 
 int persist_check(nasr_ctx* h) {
@@ -408,18 +478,18 @@ int repack(nasr_ctx* h) {
   if (h->gemm_tp) {
     for (int l = 0; l < h->L; ++l) {
       // forward operand = planes of Wx^T, input-gradient operand = planes of Wx: one pass where both are needed
-      if (l > 0 || h->npre > 0)
-        launch_tp_split2(h->P + h->off_wx[l], h->WbTP + h->off_wbtp[l], h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
-                         h->D * h->N4, nullptr, h->st);
-      else
-        launch_tp_split(h->P + h->off_wx[l], h->WfTP + h->off_wftp[l], h->D * h->N4, h->Ip[l], h->D * h->N4, true, h->st);
+      const bool back = l > 0 || h->npre > 0;
+      const float* W = h->P + h->off_wx[l];
+      if (h->tph) pl_scales(h, W, h->Ip[l], h->D * h->N4, h->D * h->N4, back ? &h->sc_wr[l] : nullptr, &h->sc_wc[l], h->st);
+      pl_split(h, W, back ? h->WbTP + h->off_wbtp[l] : nullptr, h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
+               h->D * h->N4, h->tph && back ? h->sc_wr[l].sp() : nullptr, h->tph ? h->sc_wc[l].sp() : nullptr, nullptr, h->st);
     }
     for (int i = 0; i < h->ndense; ++i) {
-      if (i > 0 || h->npre == 0)   // the first pre stage reads the features: no gradient wrt its input
-        launch_tp_split2(h->P + h->off_dw[i], h->DbTP + h->off_dbtp[i], h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i],
-                         h->dWp[i], nullptr, h->st);
-      else
-        launch_tp_split(h->P + h->off_dw[i], h->DfTP + h->off_dftp[i], h->dWp[i], h->dIp[i], h->dWp[i], true, h->st);
+      const bool back = i > 0 || h->npre == 0;   // the first pre stage reads the features: no gradient wrt its input
+      const float* W = h->P + h->off_dw[i];
+      if (h->tph) pl_scales(h, W, h->dIp[i], h->dWp[i], h->dWp[i], back ? &h->sc_dr[i] : nullptr, &h->sc_dc[i], h->st);
+      pl_split(h, W, back ? h->DbTP + h->off_dbtp[i] : nullptr, h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i], h->dWp[i],
+               h->tph && back ? h->sc_dr[i].sp() : nullptr, h->tph ? h->sc_dc[i].sp() : nullptr, nullptr, h->st);
     }
   } else if (h->gemm_bf16)
     for (int l = 0; l < h->L; ++l)
@@ -475,6 +545,22 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
     ok &= h->GTP.ensure(tp_bytes((int)R, wmax), &grew);
     ok &= h->GTTP.ensure(tp_bytes(wmax, (int)R), &grew);
     if (h->ndense) ok &= h->DTP.ensure(tp_bytes(ipmax, (int)R), &grew);
+    if (h->tph) {
+      const size_t n15 = std::max<size_t>(R, (size_t)std::max(ipmax, wmax));
+      if (n15 > h->sc15_n) {
+        ok &= h->sc15.ensure(n15);
+        if (ok) {
+          launch_fill(h->sc15.sp(), 32768.f, (int)n15, h->st);
+          launch_fill(h->sc15.ip(), 1.f / 32768.f, (int)n15, h->st);
+          h->sc15_n = n15;
+        }
+      }
+      ok &= h->sc_x0r.ensure(R) && h->sc_x0c.ensure((size_t)h->Fp);
+      ok &= h->sc_gr.ensure(R) && h->sc_gc.ensure((size_t)wmax);
+      for (int i = 0; i < h->ndense; ++i) ok &= h->sc_yr[i].ensure(R) && h->sc_yc[i].ensure((size_t)h->dWp[i]);
+      bool g2 = false;
+      ok &= h->scws.ensure(tph_scale_ws_floats((int)R, std::max(ipmax, wmax)) * 4, &g2);
+    }
   } else if (h->gemm_bf16) {
     ok &= h->X0T.ensure(R * h->Fp * 4, &grew);
     ok &= h->outT0.ensure(R * D * Hp * 4, &grew);
@@ -609,8 +695,10 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
     else
       launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
     if (h->gemm_tp) {
+      pl_scales(h, h->X0.as<float>(), T * Bp, h->Fp, h->Fp, &h->sc_x0r, &h->sc_x0c, h->st);
       if (labels && h->npre == 0)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
-        launch_tp_split(h->X0.as<float>(), h->X0TTP.as<unsigned char>(), h->Fp, T * Bp, h->Fp, true, h->st);
+        pl_split(h, h->X0.as<float>(), nullptr, h->X0TTP.as<unsigned char>(), T * Bp, h->Fp, h->Fp, nullptr,
+                 h->sc_x0c.sp(), nullptr, h->st);
     } else if (h->gemm_bf16 && labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
       launch_transpose(h->X0.as<float>(), h->X0T.as<float>(), T * Bp, h->Fp, h->Fp, T * Bp, h->st);
     HIPCHK(h, hipGetLastError());
@@ -711,12 +799,13 @@ void gemm_xproj(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
   const float* Xl = lstm_input(h, l) + (size_t)r0 * Ip;
   float* C = h->gates[l].as<float>() + (size_t)r0 * D * N4;
   if (h->gemm_tp) {
-    launch_tp_split(Xl, h->XTP.as<unsigned char>(), nr, Ip, Ip, false, st);
+    const ActScale as = lstm_in_scale(h, l);
+    pl_split(h, Xl, h->XTP.as<unsigned char>(), nullptr, nr, Ip, Ip, h->tph ? as.rs + r0 : nullptr, nullptr, nullptr, st);
     GemmTPDesc g{};
     g.A = h->XTP.as<unsigned char>(); g.B = h->WfTP + h->off_wftp[l]; g.C = C;
     g.M = nr; g.N = D * N4; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * N4;
     g.bias = h->P + h->off_bias[l]; g.split_k = 1;
-    launch_gemm_tp(g, st);
+    pl_gemm(h, g, h->tph ? as.rinv + r0 : nullptr, h->sc_wc[l].ip(), st);
   } else if (h->gemm_bf16) {
     GemmNTDesc g{};
     g.A = Xl; g.B = h->WxT + h->off_wxt[l]; g.C = C;
@@ -739,20 +828,24 @@ void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st, bool with_trans
   const float* A = dg_of(h, l) + (size_t)r0 * D * N4;
   float* C = l > 0 ? dout_of(h, l - 1) + (size_t)r0 * D * Hp : h->dYbuf[h->npre - 1].as<float>() + (size_t)r0 * h->Ip[0];
   if (h->gemm_tp) {
-    if (with_transposed && h->split2) {
-      launch_tp_split2(A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), nr, D * N4, D * N4,
-                       h->csws.as<float>(), st);
+    // fp16 planes: frame-row scales for this product, gate-column scales for the weight gradients (the whole dG when
+    // weight_grads follows, else this row range only - the pipelined path is bf16-only, see nasr_create)
+    if (with_transposed && (h->split2 || h->tph)) {
+      pl_scales(h, A, nr, D * N4, D * N4, &h->sc_gr, &h->sc_gc, st);
+      pl_split(h, A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), nr, D * N4, D * N4, h->sc_gr.sp(),
+               h->sc_gc.sp(), h->csws.as<float>(), st);
       h->gttp_layer = l;   // weight_grads(l): transposed planes and column-sum partials of dG are there
     } else {
-      launch_tp_split(A, h->GTP.as<unsigned char>(), nr, D * N4, D * N4, false, st);
+      pl_scales(h, A, nr, D * N4, D * N4, &h->sc_gr, nullptr, st);
+      pl_split(h, A, h->GTP.as<unsigned char>(), nullptr, nr, D * N4, D * N4, h->sc_gr.sp(), nullptr, nullptr, st);
     }
     GemmTPDesc g{};
     g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
     g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = h->Ip[l];
-    g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+    g.split_k = pl_pick_split(h, g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) g.split_k = 1;
-    launch_gemm_tp(g, st);
+    pl_gemm(h, g, h->sc_gr.ip(), h->tph ? h->sc_wr[l].ip() : nullptr, st);
   } else if (h->gemm_bf16) {
     GemmNTDesc g{};
     g.A = A; g.B = h->P + h->off_wx[l]; g.C = C;
@@ -771,14 +864,17 @@ void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st, bool with_trans
 // Y_i = dropout(min(relu(X W_i + b_i), clip)): one tiled-plane GEMM + the in-place epilogue of dense.hip
 int dense_forward(nasr_ctx* h, int i, const float* X) {
   const int R = h->T * h->Bp, Ip = h->dIp[i], Wp = h->dWp[i];
-  launch_tp_split(X, h->XTP.as<unsigned char>(), R, Ip, Ip, false, h->st);
+  const ActScale as = dense_in_scale(h, i);
+  pl_split(h, X, h->XTP.as<unsigned char>(), nullptr, R, Ip, Ip, h->tph ? as.rs : nullptr, nullptr, nullptr, h->st);
   GemmTPDesc g{};
   g.A = h->XTP.as<unsigned char>(); g.B = h->DfTP + h->off_dftp[i]; g.C = h->Ybuf[i].as<float>();
   g.M = R; g.N = Wp; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = Wp;
   g.bias = h->P + h->off_db[i]; g.split_k = 1;
-  launch_gemm_tp(g, h->st);
+  pl_gemm(h, g, h->tph ? as.rinv : nullptr, h->tph ? h->sc_dc[i].ip() : nullptr, h->st);
   launch_dense_act(h->Ybuf[i].as<float>(), R, h->Bp, h->B, h->dWid[i], Wp, h->cfg.relu_clip, h->cfg.dropout[i],
                    h->drop_seed, h->drop_counter, i, h->st);
+  // the stage's output feeds the next GEMM (rows = frames) and, transposed, its weight gradient (rows = features)
+  pl_scales(h, h->Ybuf[i].as<float>(), R, Wp, Wp, &h->sc_yr[i], &h->sc_yc[i], h->st);
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
 }
@@ -789,31 +885,34 @@ int dense_backward(nasr_ctx* h, int i, const float* X, float* dX) {
   const int nkb = (R + 15) / 16;
   float* dZ = h->dYbuf[i].as<float>();
   launch_dense_act_bwd(dZ, h->Ybuf[i].as<float>(), (int64_t)R * Wp, h->cfg.relu_clip, h->cfg.dropout[i], h->st);
-  if (h->split2)   // both forms of dZ (the first only when an input gradient follows) + column-sum partials in one pass
-    launch_tp_split2(dZ, dX ? h->GTP.as<unsigned char>() : nullptr, h->GTTP.as<unsigned char>(), R, Wp, Wp,
-                     h->csws.as<float>(), h->st);
+  const bool fused = h->split2 || h->tph;
+  const ActScale as = dense_in_scale(h, i);
+  pl_scales(h, dZ, R, Wp, Wp, dX ? &h->sc_gr : nullptr, &h->sc_gc, h->st);
+  if (fused)   // both forms of dZ (the first only when an input gradient follows) + column-sum partials in one pass
+    pl_split(h, dZ, dX ? h->GTP.as<unsigned char>() : nullptr, h->GTTP.as<unsigned char>(), R, Wp, Wp, h->sc_gr.sp(),
+             h->sc_gc.sp(), h->csws.as<float>(), h->st);
   else launch_tp_split(dZ, h->GTTP.as<unsigned char>(), Wp, R, Wp, true, h->st);
-  launch_tp_split(X, h->DTP.as<unsigned char>(), Ip, R, Ip, true, h->st);
+  pl_split(h, X, nullptr, h->DTP.as<unsigned char>(), R, Ip, Ip, nullptr, h->tph ? as.cs : nullptr, nullptr, h->st);
   {  // dW = X^T dZ
     GemmTPDesc g{};
     g.A = h->DTP.as<unsigned char>(); g.B = h->GTTP.as<unsigned char>(); g.C = h->G + h->off_dw[i];
     g.M = Ip; g.N = Wp; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = Wp;
-    g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+    g.split_k = pl_pick_split(h, g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-    launch_gemm_tp(g, h->st);
+    pl_gemm(h, g, h->tph ? as.cinv : nullptr, h->sc_gc.ip(), h->st);
   }
-  if (h->split2) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), Wp, h->G + h->off_db[i], h->st);
+  if (fused) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), Wp, h->G + h->off_db[i], h->st);
   else launch_colsum(dZ, R, Wp, Wp, h->G + h->off_db[i], h->csws.as<float>(), h->st);
   if (dX) {  // dX = dZ W^T
-    if (!h->split2) launch_tp_split(dZ, h->GTP.as<unsigned char>(), R, Wp, Wp, false, h->st);
+    if (!fused) launch_tp_split(dZ, h->GTP.as<unsigned char>(), R, Wp, Wp, false, h->st);
     GemmTPDesc g{};
     g.A = h->GTP.as<unsigned char>(); g.B = h->DbTP + h->off_dbtp[i]; g.C = dX;
     g.M = R; g.N = Ip; g.K = Wp; g.nkbA = (Wp + 15) / 16; g.nkbB = g.nkbA; g.ldc = Ip;
-    g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+    g.split_k = pl_pick_split(h, g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) g.split_k = 1;
-    launch_gemm_tp(g, h->st);
+    pl_gemm(h, g, h->sc_gr.ip(), h->tph ? h->sc_dr[i].ip() : nullptr, h->st);
   }
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
@@ -936,26 +1035,29 @@ int weight_grads(nasr_ctx* h, int l) {
     unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
     unsigned char* GT = h->GTTP.as<unsigned char>();
     const int nkb = (R + 15) / 16;
-    // one pass over dG: its transposed planes + 16-row partial column sums (and, in gemm_dx, its own planes)
+    // one pass over dG: its transposed planes + 64-row partial column sums (and, in gemm_dx, its own planes)
+    const bool fused = h->split2 || h->tph;
     if (h->gttp_layer != l) {
-      if (h->split2) launch_tp_split2(dG, nullptr, GT, R, D * N4, D * N4, h->csws.as<float>(), ws);
+      pl_scales(h, dG, R, D * N4, D * N4, nullptr, &h->sc_gc, ws);
+      if (fused) pl_split(h, dG, nullptr, GT, R, D * N4, D * N4, nullptr, h->sc_gc.sp(), h->csws.as<float>(), ws);
       else launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);
     }
     h->gttp_layer = -1;
-    if (l == h->L - 1) launch_tp_split(h->outb[l].as<float>(), tO[l & 1], D * Hp, R, D * Hp, true, ws);
-    if (l > 0) launch_tp_split(h->outb[l - 1].as<float>(), tO[(l - 1) & 1], D * Hp, R, D * Hp, true, ws);
-    if (l == 0 && h->npre) launch_tp_split(Xl, h->X0TTP.as<unsigned char>(), h->Ip[0], R, h->Ip[0], true, ws);
+    const ActScale ao = act_out(h), ai = lstm_in_scale(h, l);
+    if (l == h->L - 1) pl_split(h, h->outb[l].as<float>(), nullptr, tO[l & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
+    if (l > 0) pl_split(h, h->outb[l - 1].as<float>(), nullptr, tO[(l - 1) & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
+    if (l == 0 && h->npre) pl_split(h, Xl, nullptr, h->X0TTP.as<unsigned char>(), R, h->Ip[0], h->Ip[0], nullptr, ai.cs, nullptr, ws);
     {  // dWx = X^T dG
       GemmTPDesc g{};
       g.A = l == 0 ? h->X0TTP.as<unsigned char>() : tO[(l - 1) & 1];
       g.B = GT; g.C = h->G + h->off_wx[l];
       g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
-      g.split_k = gemm_tp_pick_split(g.M, g.N, g.K);
+      g.split_k = pl_pick_split(h, g.M, g.N, g.K);
       g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
       if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm_tp(g, ws);
+      pl_gemm(h, g, ai.cinv, h->sc_gc.ip(), ws);
     }
-    if (h->split2) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
+    if (fused) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
     else launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
     {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw); both directions in one launch
       GemmTPDesc g{};
@@ -963,13 +1065,13 @@ int weight_grads(nasr_ctx* h, int l) {
       g.M = Hp; g.N = N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
       g.a_kshift = -Bp;
       g.nbatch = D;
-      g.a_bstride = (size_t)(Hp / 32) * nkb * 3 * 1024; g.b_bstride = (size_t)(N4 / 32) * nkb * 3 * 1024;
+      g.a_bstride = (size_t)(Hp / 32) * pl_rb_bytes(h, nkb); g.b_bstride = (size_t)(N4 / 32) * pl_rb_bytes(h, nkb);
       g.c_bstride = (int64_t)Hp * N4;            // off_u[l*D + 1] - off_u[l*D] (build_layout)
       g.a_kshift1 = Bp;
-      g.split_k = gemm_tp_pick_split(g.M, g.N, g.K, D);
+      g.split_k = pl_pick_split(h, g.M, g.N, g.K, D);
       g.slabs = ensure_slabs(h, g.split_k * D, g.M, g.N);
       if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm_tp(g, ws);
+      pl_gemm(h, g, ao.cinv, h->sc_gc.ip(), ws, Hp, N4);
     }
   } else if (h->gemm_bf16) {
     // K-contiguous copies of the operands whose contraction index is the row (time) index
@@ -1238,6 +1340,23 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     const bool persist_cand = !(es && es[0] == '0') && persist_supported(h->Hp) && prop.multiProcessorCount == 256;
     const bool pipe_cand = h->D == 1 && h->L > 1 && !(ep && ep[0] == '0') && !persist_cand && h->ndense == 0;
     h->gemm_tp = h->gemm_bf16 && !(e && std::string(e) == "bf16") && !pipe_cand;
+    h->tph = h->gemm_tp && !(e && std::string(e) == "tp3");
+    h->sc_wr.resize(h->L); h->sc_wc.resize(h->L);
+    h->sc_dr.resize(h->ndense); h->sc_dc.resize(h->ndense); h->sc_yr.resize(h->ndense); h->sc_yc.resize(h->ndense);
+    if (h->tph) {
+      bool ok = gemm_tph_prepare() == hipSuccess, g2 = false;
+      int rmax = 1, cmax = 1;
+      for (int l = 0; l < h->L; ++l) {
+        ok = ok && h->sc_wr[l].ensure((size_t)h->Ip[l]) && h->sc_wc[l].ensure((size_t)h->D * h->N4);
+        rmax = std::max(rmax, h->Ip[l]); cmax = std::max(cmax, h->D * h->N4);
+      }
+      for (int i = 0; i < h->ndense; ++i) {
+        ok = ok && h->sc_dr[i].ensure((size_t)h->dIp[i]) && h->sc_dc[i].ensure((size_t)h->dWp[i]);
+        rmax = std::max(rmax, h->dIp[i]); cmax = std::max(cmax, h->dWp[i]);
+      }
+      ok = ok && h->scws.ensure(tph_scale_ws_floats(rmax, cmax) * 4, &g2);
+      if (!ok) return bail(NASR_ERR_HIP, "set-up of the fp16-plane GEMMs failed");
+    }
     if (h->gemm_tp) {
       size_t of = 0, ob = 0;
       h->off_wftp.resize(h->L); h->off_wbtp.resize(h->L);
@@ -1408,7 +1527,10 @@ int nasr_destroy(nasr_handle h) {
   for (auto& b : h->dYbuf) b.release();
   if (h->pctl) (void)hipFree(h->pctl);
   if (h->perr) (void)hipHostFree(h->perr);
-  for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->OTTP0, &h->OTTP1, &h->GTP, &h->GTTP}) b->release();
+  for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->OTTP0, &h->OTTP1, &h->GTP, &h->GTTP, &h->scws}) b->release();
+  for (nasr_ctx::SV* v : {&h->sc15, &h->sc_x0r, &h->sc_x0c, &h->sc_gr, &h->sc_gc}) v->release();
+  for (auto* vec : {&h->sc_yr, &h->sc_yc, &h->sc_wr, &h->sc_wc, &h->sc_dr, &h->sc_dc})
+    for (auto& v : *vec) v.release();
   for (DevBuf* b : {&h->feats_bm, &h->X0, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})

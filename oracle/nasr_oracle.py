@@ -661,6 +661,22 @@ def _deepspeech_loss_and_grads(spec, params, feats, seq_len, labels, label_len, 
     return loss, nll, grads, logits
 
 
+def deepspeech_kink_margin(spec, params, feats, seq_len, drop=None):
+    """Smallest distance of any dense-stage pre-activation of a live frame to a kink of the clipped ReLU (0 or relu_clip),
+    relative to max(1, |z|).  An fp32 implementation reproduces the oracle's ReLU masks - and with them its gradients to
+    better than one mask element - only when this margin exceeds its own forward rounding (~1e-6): tests pick inputs
+    with a clear margin instead of comparing across a discontinuity."""
+    _, fc = _deepspeech_forward(spec, params, feats, seq_len, drop)
+    T, B = fc['T'], fc['B']
+    live = (np.arange(T)[:, None] < np.asarray(seq_len)[None, :])[:, :, None]          # [T,B,1]
+    worst = np.inf
+    for (x, z, W_, m, pr) in list(fc['dense']) + ([fc['post']] if fc['post'] is not None else []):
+        d = np.minimum(np.abs(z), np.abs(z - spec.relu_clip)) / np.maximum(1.0, np.abs(z))
+        d = np.where(live & m, d, np.inf)
+        worst = min(worst, float(d.min()))
+    return worst
+
+
 def network_loss_and_grads(spec: ModelSpec, params, feats, seq_len, labels, label_len, drop=None):
     """loss = reduce_mean(ctc_loss) (networks/tfnetwork.py:59) and d loss / d every variable,
     in TF variable order.  Returns (loss, nll[B], grads list, logits)."""

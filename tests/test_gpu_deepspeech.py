@@ -49,8 +49,20 @@ def case_id(c):
 @pytest.mark.parametrize("case", CASES, ids=case_id)
 def test_deepspeech_family_matches_oracle(case):
     spec, B, T = case
-    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=3 * B + T, var_len=True, Lmin=1, Lmax=max(1, T // 5))
     params = rand_params(spec, 4)
+    seed, counter = 4567, 11
+    # the clipped ReLU is not differentiable at 0 and at the clip: a pre-activation within fp32 rounding (~1e-6 relative)
+    # of a kink gets either mask in any fp32 implementation, and one flipped element moves a small gradient tensor by
+    # 1e-3.  With 10^5..10^6 pre-activations some always lie within 1e-5: take, of 24 inputs, the one whose nearest
+    # pre-activation is furthest from a kink, and require a clear margin.
+    best = (-1.0, None)
+    for data_seed in range(3 * B + T, 3 * B + T + 24):
+        batch = O.synth_batch(spec, B, T, seed=data_seed, var_len=True, Lmin=1, Lmax=max(1, T // 5))
+        margin = O.deepspeech_kink_margin(spec, params, batch[0], batch[1], drop=(seed, counter))
+        if margin > best[0]:
+            best = (margin, batch)
+    assert best[0] > 1e-5, best[0]
+    feats, seq_len, labels, label_len = best[1]
     e = make_engine(spec)
     names = [n for n, _, _, _ in e.tensors()]
     assert names == [n for n, _ in spec.param_shapes()]        # creation order of networks/deepspeech.py
@@ -58,7 +70,6 @@ def test_deepspeech_family_matches_oracle(case):
     e.set_params(O.flatten(params))
     np.testing.assert_array_equal(e.get_params(), O.flatten(params).astype(np.float32))
 
-    seed, counter = 4567, 11
     loss_o, nll_o, grads_o, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len,
                                                                 drop=(seed, counter))
     e.set_dropout_state(seed, counter)

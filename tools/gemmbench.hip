@@ -3,10 +3,12 @@
 #include "../neuralasr_amd/csrc/gemm.hip"
 #include "../neuralasr_amd/csrc/gemm_bf16.hip"
 #include "../neuralasr_amd/csrc/gemm_tp.hip"
+#include "../neuralasr_amd/csrc/gemm_tph.hip"
 #include "../neuralasr_amd/csrc/optim.hip"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace nasr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -107,6 +109,100 @@ int main() {
     }
     printf("tp     %s split %d : %.3f ms  %.1f TF-equiv (+ %.3f ms to split both operands)  rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, split, best,
            2.0 * c.M * c.N * c.K / best / 1e9, tsplit, sqrt(num / den), mx);
+  }
+  // ---- two fp16 planes + three products (gemm_tph.hip): the same shapes, operands scaled per row from measured maxima
+  {
+    CK(gemm_tph_prepare());
+    unsigned char *HA, *HB;
+    CK(hipMalloc(&HA, tph_bytes(R, 4096))); CK(hipMalloc(&HB, tph_bytes(4096, R)));
+    float *sa, *ia, *sb, *ib, *sws;
+    CK(hipMalloc(&sa, 8192 * 4)); CK(hipMalloc(&ia, 8192 * 4)); CK(hipMalloc(&sb, 8192 * 4)); CK(hipMalloc(&ib, 8192 * 4));
+    CK(hipMalloc(&sws, tph_scale_ws_floats(8192, 8192) * 4));
+    for (auto& c : nts) {
+      if ((size_t)c.M * c.K > c.a_elems || (size_t)c.N * c.K > c.b_elems) continue;
+      GemmDesc f{}; f.A = c.A; f.B = c.B; f.C = O2; f.M = c.M; f.N = c.N; f.K = c.K; f.lda = c.K; f.ldb = c.K; f.ldc = c.N;
+      f.b_col = true; f.a_rows = c.M; f.split_k = 1;
+      launch_gemm(f, st);
+      float tsplit = 1e9f;
+      for (int i = 0; i < 3; ++i) {
+        CK(hipEventRecord(a, st));
+        launch_tph_scales(c.A, c.M, c.K, c.K, sa, ia, nullptr, nullptr, sws, st);
+        launch_tph_split2(c.A, HA, nullptr, c.M, c.K, c.K, sa, 1.f, nullptr, 1.f, nullptr, st);
+        launch_tph_scales(c.B, c.N, c.K, c.K, sb, ib, nullptr, nullptr, sws, st);
+        launch_tph_split2(c.B, HB, nullptr, c.N, c.K, c.K, sb, 1.f, nullptr, 1.f, nullptr, st);
+        CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); tsplit = ms < tsplit ? ms : tsplit;
+      }
+      GemmTPHDesc g{}; g.A = HA; g.B = HB; g.C = O; g.M = c.M; g.N = c.N; g.K = c.K; g.nkbA = (c.K + 15) / 16; g.nkbB = g.nkbA; g.ldc = c.N;
+      g.a_inv = ia; g.b_inv = ib;
+      g.split_k = gemm_tph_pick_split(c.M, c.N, c.K); g.slabs = slabs;
+      if ((size_t)g.split_k * c.M * c.N > (size_t)8 * 1024 * 4096) { printf("slabs too small\n"); continue; }
+      CK(hipMemset(O, 0xff, (size_t)c.M * c.N * 4));
+      launch_gemm_tph(g, st); CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+      std::vector<float> h1((size_t)c.M * c.N), h2((size_t)c.M * c.N);
+      CK(hipMemcpy(h1.data(), O, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), O2, h2.size() * 4, hipMemcpyDeviceToHost));
+      double num = 0, den = 0, mx = 0;
+      for (size_t i = 0; i < h1.size(); ++i) { double d = (double)h1[i] - h2[i]; num += d * d; den += (double)h2[i] * h2[i]; if (!(fabs(d) <= mx)) mx = fabs(d); }
+      float best = 1e9f;
+      for (int i = 0; i < 10; ++i) {
+        CK(hipEventRecord(a, st)); launch_gemm_tph(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+      }
+      printf("tph    %s split %d : %.3f ms  %.1f TF-equiv (+ %.3f ms for scales + planes of both operands)  rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, g.split_k, best,
+             2.0 * c.M * c.N * c.K / best / 1e9, tsplit, sqrt(num / den), mx);
+    }
+  }
+  {  // fp16-plane helpers against the host: scales (rows and columns of a ragged, wide-range matrix) and column sums
+    const int rr = 960, kk = 1000, ld = 1024;
+    std::vector<float> hx((size_t)rr * ld);
+    CK(hipMemcpy(hx.data(), X, hx.size() * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < rr; ++r) for (int c = 0; c < kk; ++c) hx[(size_t)r * ld + c] *= ldexpf(1.f, (r * 7 + c * 3) % 40 - 20);
+    for (int c = 0; c < kk; ++c) hx[(size_t)5 * ld + c] = 0.f;       // an all-zero row
+    float* dx; CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    float *rs, *ri, *cs, *ci, *ws2, *cpart, *csum;
+    CK(hipMalloc(&rs, rr * 4)); CK(hipMalloc(&ri, rr * 4)); CK(hipMalloc(&cs, kk * 4)); CK(hipMalloc(&ci, kk * 4));
+    CK(hipMalloc(&ws2, tph_scale_ws_floats(rr, kk) * 4)); CK(hipMalloc(&cpart, (size_t)tp_split2_parts(rr) * kk * 4)); CK(hipMalloc(&csum, kk * 4));
+    unsigned char *pn, *pt; CK(hipMalloc(&pn, tph_bytes(rr, kk))); CK(hipMalloc(&pt, tph_bytes(kk, rr)));
+    launch_tph_scales(dx, rr, kk, ld, rs, ri, cs, ci, ws2, st);
+    launch_tph_split2(dx, pn, pt, rr, kk, ld, rs, 1.f, cs, 1.f, cpart, st);
+    launch_colsum_parts(cpart, tp_split2_parts(rr), kk, csum, st);
+    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+    std::vector<float> hrs(rr), hri(rr), hcs(kk), hci(kk), hsum(kk);
+    CK(hipMemcpy(hrs.data(), rs, rr * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hri.data(), ri, rr * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hcs.data(), cs, kk * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hci.data(), ci, kk * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hsum.data(), csum, kk * 4, hipMemcpyDeviceToHost));
+    int badr = 0, badc = 0; double se = 0, sn = 0;
+    for (int r = 0; r < rr; ++r) {
+      float m = 0; for (int c = 0; c < kk; ++c) m = fmaxf(m, fabsf(hx[(size_t)r * ld + c]));
+      const float v = m * hrs[r];
+      if (!(m == 0 ? hrs[r] == 1.f : (v >= 16384.f && v < 32768.f)) || hrs[r] * hri[r] != 1.f) ++badr;
+    }
+    for (int c = 0; c < kk; ++c) {
+      float m = 0; double sum = 0;
+      for (int r = 0; r < rr; ++r) { m = fmaxf(m, fabsf(hx[(size_t)r * ld + c])); sum += hx[(size_t)r * ld + c]; }
+      const float v = m * hcs[c];
+      if (!(v >= 16384.f && v < 32768.f) || hcs[c] * hci[c] != 1.f) ++badc;
+      se += (hsum[c] - sum) * (hsum[c] - sum); sn += sum * sum;
+    }
+    // planes back to values: element (r, c) of the normal planes
+    std::vector<unsigned char> hp(tph_bytes(rr, kk)), hq(tph_bytes(kk, rr));
+    CK(hipMemcpy(hp.data(), pn, hp.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(hq.data(), pt, hq.size(), hipMemcpyDeviceToHost));
+    auto at = [&](const std::vector<unsigned char>& pl, int nkb, int row, int k) {
+      const size_t tile = ((size_t)(row >> 5) * nkb + (k >> 4)) * 2 * 1024;
+      const int r = row & 31, hh = (k >> 3) & 1, e = k & 7;
+      const size_t off = tile + ((((r << 1) | (hh ^ ((r >> 3) & 1))) << 4)) + e * 2;
+      _Float16 h1, h2; memcpy(&h1, &pl[off], 2); memcpy(&h2, &pl[off + 1024], 2);
+      return (double)(float)h1 + (double)(float)h2;
+    };
+    double worst_n = 0, worst_t = 0;
+    for (int r = 0; r < rr; r += 7) for (int c = 0; c < kk; c += 3) {
+      const double x = hx[(size_t)r * ld + c];
+      if (x == 0) continue;
+      worst_n = fmax(worst_n, fabs(at(hp, (kk + 15) / 16, r, c) / hrs[r] - x) / fabs(x));
+      worst_t = fmax(worst_t, fabs(at(hq, (rr + 15) / 16, c, r) / hcs[c] - x) / fabs(x));
+    }
+    printf("fp16 planes of a 960x1000 matrix spanning 2^-20..2^20: %d / %d bad row / column scales, column sums rel %.1e, worst element error %.1e (row-scaled planes) %.1e (column-scaled planes)\n",
+           badr, badc, sqrt(se / sn), worst_n, worst_t);
   }
   // block-tile height x K split for the layer-0 weight gradient (M = 576 = 2.25 x 256 = 3 x 192)
   {
