@@ -87,6 +87,51 @@ def test_forward_loss_grads_match_oracle(case):
     e.close()
 
 
+@pytest.mark.parametrize("scaling", ['tiny', 'huge', 'mixed', 'sparse'])
+def test_operand_scaling_of_the_fp16_plane_gemms(scaling):
+    """The GEMMs split every operand into two fp16 planes under a power-of-two scale per operand row, measured on the
+    device (gemm_tph.hip).  Inputs and weights far outside fp16's range, utterances 10 decades apart in one batch, and
+    all-zero rows / columns must come out with the fp32 tolerances of the test above."""
+    spec = O.ModelSpec(40, 96, 2, True, 'concat', 11)
+    B, T = 6, 45
+    F = spec.feature_size
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=77, var_len=True, Lmin=1, Lmax=9)
+    params = rand_params(spec, 6)         # l0/fw/kernel [F+H, 4H], bias, l0/bw/kernel, bias, l1/..., W, b
+    if scaling == 'tiny':          # features ~1e-7, first-layer input weights ~1e+5: products of order one
+        feats = feats * 1e-7
+        params[0][:F] *= 1e5
+        params[2][:F] *= 1e5
+    elif scaling == 'huge':        # features ~1e+6 (65504 is fp16's largest number), weights ~1e-7
+        feats = feats * 1e6
+        params[0][:F] *= 1e-7
+        params[2][:F] *= 1e-7
+    elif scaling == 'mixed':       # utterances 10 decades apart: one scale per frame row, one per feature column
+        feats = feats * np.logspace(-5, 5, B)[:, None, None]
+        params[0][:F] *= 1e-3
+        params[2][:F] *= 1e-3
+    else:                          # all-zero feature columns, an all-zero utterance, zero weight rows and columns
+        feats[:, :, 5:17] = 0.0
+        feats[2] = 0.0
+        params[0][3:9] = 0.0
+        params[0][:, 10:50] = 0.0
+        params[4][:, :96] = 0.0
+    e = make_engine(spec)
+    e.set_params(O.flatten(params))
+    pf = [np.asarray(p, np.float32).astype(np.float64) for p in params]          # what the engine holds
+    ff = np.asarray(feats, np.float32).astype(np.float64)
+    loss_o, nll_o, grads_o, logits_o = O.network_loss_and_grads(spec, pf, ff, seq_len, labels, label_len)
+    logits = e.forward(ff.astype(np.float32), seq_len)
+    np.testing.assert_allclose(logits, logits_o, atol=1e-4)
+    loss, nll, grads = e.loss_and_grads(ff.astype(np.float32), seq_len, labels, label_len)
+    assert np.isfinite(grads).all()
+    assert loss == pytest.approx(loss_o, rel=2e-5)
+    gscale = np.linalg.norm(O.flatten(grads_o))
+    for (name, off, r, c), g_o in zip(e.tensors(), grads_o):
+        g = grads[off:off + r * c].reshape(g_o.shape)
+        assert np.linalg.norm(g - g_o) <= 1e-4 * np.linalg.norm(g_o) + 1e-6 * gscale, name
+    e.close()
+
+
 @pytest.mark.parametrize("case", CASES[:5], ids=case_id)
 def test_greedy_decode_identical(case):
     spec, B, T, var = case
