@@ -136,6 +136,102 @@ void launch_tph_scales(const float* src, int rows, int K, int ld, float* row_sca
   if (col_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((K + 255) / 256), dim3(256), 0, st, cp, (int)grid.y, K, col_scale, col_inv);
 }
 
+// ---- the same for several (small) matrices in two launches: the weights, once per optimiser step
+struct ScaleJobs {
+  const float* src[TPH_MAX_JOBS];
+  int rows[TPH_MAX_JOBS], K[TPH_MAX_JOBS], ld[TPH_MAX_JOBS];
+  float* rowpart[TPH_MAX_JOBS];   // NULL: no row scales wanted
+  float* colpart[TPH_MAX_JOBS];
+  float *rs[TPH_MAX_JOBS], *ri[TPH_MAX_JOBS], *cs[TPH_MAX_JOBS], *ci[TPH_MAX_JOBS];
+  int gx[TPH_MAX_JOBS], gy[TPH_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void absmax_part_batch_kernel(ScaleJobs j) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x >= j.gx[z] || (int)blockIdx.y >= j.gy[z]) return;
+  // same body as absmax_part_kernel on job z
+  __shared__ float rm[64], cm[4][64];
+  const float* __restrict__ src = j.src[z];
+  const int rows = j.rows[z], K = j.K[z], ld = j.ld[z];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int cq = t & 15, rq = t >> 4;
+  float cmax[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = rq + 16 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows) {
+      const float* s = src + (size_t)(r0 + r) * ld + c0 + 4 * cq;
+      if (c0 + 4 * cq + 4 <= K) v = *reinterpret_cast<const float4*>(s);
+      else {
+        if (c0 + 4 * cq < K) v.x = s[0];
+        if (c0 + 4 * cq + 1 < K) v.y = s[1];
+        if (c0 + 4 * cq + 2 < K) v.z = s[2];
+      }
+    }
+    v.x = fabsf(v.x); v.y = fabsf(v.y); v.z = fabsf(v.z); v.w = fabsf(v.w);
+    cmax[0] = fmaxf(cmax[0], v.x); cmax[1] = fmaxf(cmax[1], v.y); cmax[2] = fmaxf(cmax[2], v.z); cmax[3] = fmaxf(cmax[3], v.w);
+    float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+    if (cq == 0) rm[r] = m;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float m = cmax[q];
+    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    if ((t & 63) < 16) cm[t >> 6][4 * cq + q] = m;
+  }
+  __syncthreads();
+  if (t < 64) {
+    if (j.rowpart[z] && r0 + t < rows) j.rowpart[z][(size_t)blockIdx.x * rows + r0 + t] = rm[t];
+    if (c0 + t < K) j.colpart[z][(size_t)blockIdx.y * K + c0 + t] = fmaxf(fmaxf(cm[0][t], cm[1][t]), fmaxf(cm[2][t], cm[3][t]));
+  }
+}
+__global__ __launch_bounds__(256) void scale_final_batch_kernel(ScaleJobs j) {
+  const int z = blockIdx.z, which = blockIdx.y;           // which: 0 = rows, 1 = columns
+  const float* part = which ? j.colpart[z] : j.rowpart[z];
+  if (!part) return;
+  const int n = which ? j.K[z] : j.rows[z], nparts = which ? j.gy[z] : j.gx[z];
+  float* scale = which ? j.cs[z] : j.rs[z];
+  float* inv = which ? j.ci[z] : j.ri[z];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float m = 0.f;
+    for (int k = 0; k < nparts; ++k) m = fmaxf(m, part[(size_t)k * n + i]);
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e); else e = 15;
+    e = max(-100, min(100, e));
+    scale[i] = ldexpf(1.f, 15 - e);
+    inv[i] = ldexpf(1.f, e - 15);
+  }
+}
+
+size_t tph_scale_batch_ws_floats(const TphScaleJob* jobs, int n) {
+  size_t f = 0;
+  for (int i = 0; i < n; ++i) f += tph_scale_ws_floats(jobs[i].rows, jobs[i].K);
+  return f;
+}
+
+void launch_tph_scales_batch(const TphScaleJob* jobs, int n, float* ws, hipStream_t st) {
+  for (int j0 = 0; j0 < n; j0 += TPH_MAX_JOBS) {
+    const int m = n - j0 < TPH_MAX_JOBS ? n - j0 : TPH_MAX_JOBS;
+    ScaleJobs sj{};
+    int gxm = 1, gym = 1, nmax = 1;
+    for (int i = 0; i < m; ++i) {
+      const TphScaleJob& q = jobs[j0 + i];
+      sj.src[i] = q.src; sj.rows[i] = q.rows; sj.K[i] = q.K; sj.ld[i] = q.ld;
+      sj.gx[i] = (q.K + 63) / 64; sj.gy[i] = (q.rows + 63) / 64;
+      sj.rowpart[i] = q.row_scale ? ws : nullptr;
+      sj.colpart[i] = ws + (size_t)sj.gx[i] * q.rows;
+      ws += tph_scale_ws_floats(q.rows, q.K);
+      sj.rs[i] = q.row_scale; sj.ri[i] = q.row_inv; sj.cs[i] = q.col_scale; sj.ci[i] = q.col_inv;
+      gxm = gxm > sj.gx[i] ? gxm : sj.gx[i]; gym = gym > sj.gy[i] ? gym : sj.gy[i];
+      nmax = nmax > q.rows ? nmax : q.rows; nmax = nmax > q.K ? nmax : q.K;
+    }
+    hipLaunchKernelGGL(absmax_part_batch_kernel, dim3(gxm, gym, m), dim3(256), 0, st, sj);
+    hipLaunchKernelGGL(scale_final_batch_kernel, dim3((nmax + 255) / 256, 2, m), dim3(256), 0, st, sj);
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

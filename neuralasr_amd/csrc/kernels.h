@@ -89,6 +89,12 @@ size_t tph_bytes(int rows, int K);
 size_t tph_scale_ws_floats(int rows, int K);
 void launch_tph_scales(const float* src, int rows, int K, int ld, float* row_scale, float* row_inv, float* col_scale,
                        float* col_inv, float* ws, hipStream_t st);
+// several matrices in two launches (column scales always, row scales when row_scale != NULL); ws:
+// tph_scale_batch_ws_floats(jobs, n) floats
+constexpr int TPH_MAX_JOBS = 8;
+struct TphScaleJob { const float* src; int rows, K, ld; float *row_scale, *row_inv, *col_scale, *col_inv; };
+size_t tph_scale_batch_ws_floats(const TphScaleJob* jobs, int n);
+void launch_tph_scales_batch(const TphScaleJob* jobs, int n, float* ws, hipStream_t st);
 void launch_fill(float* p, float v, int n, hipStream_t st);
 // one pass over src [rows][K]: tpN = planes of src (scale per src row: row_scale[] or the constant rs), tpT = planes of its
 // transpose (scale per src column: col_scale[] or cs); either may be NULL; colpart as in launch_tp_split2

@@ -476,18 +476,30 @@ int repack(nasr_ctx* h) {
       }
   }
   if (h->gemm_tp) {
+    if (h->tph) {   // scales of every weight matrix in two launches
+      std::vector<TphScaleJob> jobs;
+      for (int l = 0; l < h->L; ++l) {
+        const bool back = l > 0 || h->npre > 0;
+        jobs.push_back({h->P + h->off_wx[l], h->Ip[l], h->D * h->N4, h->D * h->N4, back ? h->sc_wr[l].sp() : nullptr,
+                        back ? h->sc_wr[l].ip() : nullptr, h->sc_wc[l].sp(), h->sc_wc[l].ip()});
+      }
+      for (int i = 0; i < h->ndense; ++i) {
+        const bool back = i > 0 || h->npre == 0;
+        jobs.push_back({h->P + h->off_dw[i], h->dIp[i], h->dWp[i], h->dWp[i], back ? h->sc_dr[i].sp() : nullptr,
+                        back ? h->sc_dr[i].ip() : nullptr, h->sc_dc[i].sp(), h->sc_dc[i].ip()});
+      }
+      launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
+    }
     for (int l = 0; l < h->L; ++l) {
       // forward operand = planes of Wx^T, input-gradient operand = planes of Wx: one pass where both are needed
       const bool back = l > 0 || h->npre > 0;
       const float* W = h->P + h->off_wx[l];
-      if (h->tph) pl_scales(h, W, h->Ip[l], h->D * h->N4, h->D * h->N4, back ? &h->sc_wr[l] : nullptr, &h->sc_wc[l], h->st);
       pl_split(h, W, back ? h->WbTP + h->off_wbtp[l] : nullptr, h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
                h->D * h->N4, h->tph && back ? h->sc_wr[l].sp() : nullptr, h->tph ? h->sc_wc[l].sp() : nullptr, nullptr, h->st);
     }
     for (int i = 0; i < h->ndense; ++i) {
       const bool back = i > 0 || h->npre == 0;   // the first pre stage reads the features: no gradient wrt its input
       const float* W = h->P + h->off_dw[i];
-      if (h->tph) pl_scales(h, W, h->dIp[i], h->dWp[i], h->dWp[i], back ? &h->sc_dr[i] : nullptr, &h->sc_dc[i], h->st);
       pl_split(h, W, back ? h->DbTP + h->off_dbtp[i] : nullptr, h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i], h->dWp[i],
                h->tph && back ? h->sc_dr[i].sp() : nullptr, h->tph ? h->sc_dc[i].sp() : nullptr, nullptr, h->st);
     }
@@ -1354,7 +1366,10 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
         ok = ok && h->sc_dr[i].ensure((size_t)h->dIp[i]) && h->sc_dc[i].ensure((size_t)h->dWp[i]);
         rmax = std::max(rmax, h->dIp[i]); cmax = std::max(cmax, h->dWp[i]);
       }
-      ok = ok && h->scws.ensure(tph_scale_ws_floats(rmax, cmax) * 4, &g2);
+      size_t wsf = 0;     // launch_tph_scales_batch works on all weight matrices at once
+      for (int l = 0; l < h->L; ++l) wsf += tph_scale_ws_floats(h->Ip[l], h->D * h->N4);
+      for (int i = 0; i < h->ndense; ++i) wsf += tph_scale_ws_floats(h->dIp[i], h->dWp[i]);
+      ok = ok && h->scws.ensure(std::max(wsf, tph_scale_ws_floats(rmax, cmax)) * 4, &g2);
       if (!ok) return bail(NASR_ERR_HIP, "set-up of the fp16-plane GEMMs failed");
     }
     if (h->gemm_tp) {
