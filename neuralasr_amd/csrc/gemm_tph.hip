@@ -110,17 +110,29 @@ __global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restric
   }
 }
 
+// 64 lines per block, 4 threads per line (partial rows q, q+4, ...) combined through LDS
+__device__ __forceinline__ void scale_final_body(const float* __restrict__ part, int nparts, int n, float* __restrict__ scale,
+                                                 float* __restrict__ inv, int block) {
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = block * 64 + cx;
+  float m = 0.f;
+  if (i < n)
+    for (int k = q; k < nparts; k += 4) m = fmaxf(m, part[(size_t)k * n + i]);
+  sm[q][cx] = m;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    m = fmaxf(fmaxf(sm[0][cx], sm[1][cx]), fmaxf(sm[2][cx], sm[3][cx]));
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e); else e = 15;     // m = f * 2^e, f in [0.5, 1)
+    e = max(-100, min(100, e));
+    scale[i] = ldexpf(1.f, 15 - e);
+    inv[i] = ldexpf(1.f, e - 15);
+  }
+}
 __global__ __launch_bounds__(256) void scale_final_kernel(const float* __restrict__ part, int nparts, int n,
                                                           float* __restrict__ scale, float* __restrict__ inv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float m = 0.f;
-  for (int k = 0; k < nparts; ++k) m = fmaxf(m, part[(size_t)k * n + i]);
-  int e = 0;
-  if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e); else e = 15;     // m = f * 2^e, f in [0.5, 1)
-  e = max(-100, min(100, e));
-  scale[i] = ldexpf(1.f, 15 - e);
-  inv[i] = ldexpf(1.f, e - 15);
+  scale_final_body(part, nparts, n, scale, inv, blockIdx.x);
 }
 
 size_t tph_scale_ws_floats(int rows, int K) { return (size_t)((K + 63) / 64) * rows + (size_t)((rows + 63) / 64) * K; }
@@ -132,8 +144,8 @@ void launch_tph_scales(const float* src, int rows, int K, int ld, float* row_sca
   float* rp = row_scale ? ws : nullptr;
   float* cp = col_scale ? ws + (size_t)grid.x * rows : nullptr;
   hipLaunchKernelGGL(absmax_part_kernel, grid, dim3(256), 0, st, src, rows, K, ld, rp, cp);
-  if (row_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, rp, (int)grid.x, rows, row_scale, row_inv);
-  if (col_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((K + 255) / 256), dim3(256), 0, st, cp, (int)grid.y, K, col_scale, col_inv);
+  if (row_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((rows + 63) / 64), dim3(256), 0, st, rp, (int)grid.x, rows, row_scale, row_inv);
+  if (col_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((K + 63) / 64), dim3(256), 0, st, cp, (int)grid.y, K, col_scale, col_inv);
 }
 
 // ---- the same for several (small) matrices in two launches: the weights, once per optimiser step
@@ -190,19 +202,9 @@ __global__ __launch_bounds__(256) void absmax_part_batch_kernel(ScaleJobs j) {
 __global__ __launch_bounds__(256) void scale_final_batch_kernel(ScaleJobs j) {
   const int z = blockIdx.z, which = blockIdx.y;           // which: 0 = rows, 1 = columns
   const float* part = which ? j.colpart[z] : j.rowpart[z];
-  if (!part) return;
   const int n = which ? j.K[z] : j.rows[z], nparts = which ? j.gy[z] : j.gx[z];
-  float* scale = which ? j.cs[z] : j.rs[z];
-  float* inv = which ? j.ci[z] : j.ri[z];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float m = 0.f;
-    for (int k = 0; k < nparts; ++k) m = fmaxf(m, part[(size_t)k * n + i]);
-    int e = 0;
-    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e); else e = 15;
-    e = max(-100, min(100, e));
-    scale[i] = ldexpf(1.f, 15 - e);
-    inv[i] = ldexpf(1.f, e - 15);
-  }
+  if (!part || (int)blockIdx.x * 64 >= n) return;         // block-uniform
+  scale_final_body(part, nparts, n, which ? j.cs[z] : j.rs[z], which ? j.ci[z] : j.ri[z], blockIdx.x);
 }
 
 size_t tph_scale_batch_ws_floats(const TphScaleJob* jobs, int n) {
@@ -228,7 +230,7 @@ void launch_tph_scales_batch(const TphScaleJob* jobs, int n, float* ws, hipStrea
       nmax = nmax > q.rows ? nmax : q.rows; nmax = nmax > q.K ? nmax : q.K;
     }
     hipLaunchKernelGGL(absmax_part_batch_kernel, dim3(gxm, gym, m), dim3(256), 0, st, sj);
-    hipLaunchKernelGGL(scale_final_batch_kernel, dim3((nmax + 255) / 256, 2, m), dim3(256), 0, st, sj);
+    hipLaunchKernelGGL(scale_final_batch_kernel, dim3((nmax + 63) / 64, 2, m), dim3(256), 0, st, sj);
   }
 }
 

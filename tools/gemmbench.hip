@@ -194,14 +194,17 @@ int main() {
       _Float16 h1, h2; memcpy(&h1, &pl[off], 2); memcpy(&h2, &pl[off + 1024], 2);
       return (double)(float)h1 + (double)(float)h2;
     };
+    // an element within 2^-18 of its line's maximum keeps 2^-24 relative; below that the error is 2^-40 of the maximum
     double worst_n = 0, worst_t = 0;
     for (int r = 0; r < rr; r += 7) for (int c = 0; c < kk; c += 3) {
       const double x = hx[(size_t)r * ld + c];
       if (x == 0) continue;
-      worst_n = fmax(worst_n, fabs(at(hp, (kk + 15) / 16, r, c) / hrs[r] - x) / fabs(x));
-      worst_t = fmax(worst_t, fabs(at(hq, (rr + 15) / 16, c, r) / hcs[c] - x) / fabs(x));
+      const double bn = fmax(fabs(x) * ldexp(1.0, -24), ldexp(1.0, -40) * 32768.0 / hrs[r]);
+      const double bt = fmax(fabs(x) * ldexp(1.0, -24), ldexp(1.0, -40) * 32768.0 / hcs[c]);
+      worst_n = fmax(worst_n, fabs(at(hp, (kk + 15) / 16, r, c) / hrs[r] - x) / bn);
+      worst_t = fmax(worst_t, fabs(at(hq, (rr + 15) / 16, c, r) / hcs[c] - x) / bt);
     }
-    printf("fp16 planes of a 960x1000 matrix spanning 2^-20..2^20: %d / %d bad row / column scales, column sums rel %.1e, worst element error %.1e (row-scaled planes) %.1e (column-scaled planes)\n",
+    printf("fp16 planes of a 960x1000 matrix spanning 2^-20..2^20: %d / %d bad row / column scales, column sums rel %.1e, worst element error / bound max(2^-24 |x|, 2^-40 line max): %.2f (row-scaled planes) %.2f (column-scaled planes)\n",
            badr, badc, sqrt(se / sn), worst_n, worst_t);
   }
   // block-tile height x K split for the layer-0 weight gradient (M = 576 = 2.25 x 256 = 3 x 192)
