@@ -3,12 +3,13 @@
 //     C[M,N] = A[M,K] * B[N,K]^T (+bias[n])
 //
 // x*s = h1 + h2 with h1 = fp16(x*s), h2 = fp16(x*s - h1): the two 11-bit significands and the sign of h2 hold x*s to
-// 2^-24 relative - fp32's own rounding - PROVIDED neither part leaves fp16's exponent range.  That is what the scale s
+// 2^-23 relative (measured bound, tools/gemmbench.hip) - fp32's own rounding class - PROVIDED neither part leaves
+// fp16's exponent range.  That is what the scale s
 // is for: a power of two per row of the operand (constant along the contraction, so it factors out of the sum and the
 // epilogue multiplies by 1/(s_row * s_col), exactly) chosen so that the row's largest magnitude lands in [2^14, 2^15).
-// Elements down to 2^-18 of their row's maximum keep all 24 bits; below that the error is absolute, 2^-40 of the row
+// Elements down to 2^-18 of their row's maximum keep all those bits; below that the error is absolute, 2^-39 of the row
 // maximum (fp16 subnormal spacing 2^-24 against a maximum of 2^15) - far under what fp32 accumulation of the same dot
-// product loses.  x*y = h1*h1' + h1*h2' + h2*h1' + O(2^-24 xy), accumulated in fp32 by v_mfma_f32_32x32x16_f16: the same
+// product loses.  x*y = h1*h1' + h1*h2' + h2*h1' + O(2^-22 xy), accumulated in fp32 by v_mfma_f32_32x32x16_f16: the same
 // accuracy class as the six bf16 products (bf16's 8-bit exponent needs no scale, its 8-bit significand three parts), at
 // half the matrix-core work and two thirds of the operand bytes.
 //

@@ -194,7 +194,8 @@ int main() {
       _Float16 h1, h2; memcpy(&h1, &pl[off], 2); memcpy(&h2, &pl[off + 1024], 2);
       return (double)(float)h1 + (double)(float)h2;
     };
-    // an element within 2^-18 of its line's maximum keeps 2^-24 relative; below that the error is 2^-40 of the maximum
+    // an element within 2^-18 of its line's maximum keeps 2^-23 relative; below that the error is 2^-39 of the maximum
+    // (the printed ratio is against half of that bound: <= 2.00 expected)
     double worst_n = 0, worst_t = 0;
     for (int r = 0; r < rr; r += 7) for (int c = 0; c < kk; c += 3) {
       const double x = hx[(size_t)r * ld + c];
