@@ -326,6 +326,11 @@ def main():
                        'batch_per_gpu': B, 'frames': T, 'var_len': bool(args.var_len),
                        'parallelism': f'dp{world}', 'hipgraph': not args.no_graph,
                        'recurrence': eng.recurrence_mode,
+                       'gemm': {'tp': 'fp32 products from 2 fp16 planes x 3 MFMA products, fp32 accumulation, power-of-two '
+                                      'row scales (gemm_tph.hip)',
+                                'tp3': 'fp32 products from 3 bf16 planes x 6 MFMA products, fp32 accumulation (gemm_tp.hip)',
+                                'bf16': 'as tp3, operands split inside the GEMM (gemm_bf16.hip)',
+                                'f32': 'fp32 MFMA (gemm.hip)'}.get(os.environ.get('NASR_GEMM', 'tp'), 'tp'),
                        'allreduce': (ar_mode if world > 1 else None)},
             'loss': loss,
             'roofline': {'bound': 'hbm', 'kernel': kname,
