@@ -61,6 +61,33 @@ def algorithmic_bytes(spec, B, T):
     return A, W, R
 
 
+def algorithmic_flops(spec, B, T):
+    """SURVEY.md §8d "ALGORITHMIC FLOPs per frame": forward = input + recurrent contractions of every layer, the dense
+    stages and the projection; backward = 2x forward minus the input-gradient GEMM of whatever reads the features.
+    Returns (dense FLOPs per step: everything hoisted out of the time loop, recurrent FLOPs per step)."""
+    N = B * T
+    D, H, C = spec.dirs, spec.hidden, spec.num_classes
+    rows = 2 if (spec.bidirectional and spec.merge == 'stack_reshape') else 1
+    hoisted, rec, first = 0, 0, None
+    widths = [(spec.feature_size if i == 0 else spec.pre[i - 1], w) for i, w in enumerate(spec.pre)]
+    for i_w, o_w in widths:
+        hoisted += 2 * i_w * o_w
+        first = first if first is not None else 2 * i_w * o_w
+    for l in range(spec.num_layers):
+        I = spec.layer_input(l)
+        hoisted += 2 * I * 4 * H * D
+        first = first if first is not None else 2 * I * 4 * H * D
+        rec += 2 * H * 4 * H * D
+    if spec.post:
+        hoisted += 2 * spec.proj_in * spec.post
+    hoisted += 2 * (spec.post or spec.proj_in) * C * rows
+    # backward: weight gradient + input gradient for every contraction (2x), no input gradient for the first one; the
+    # recurrent weight gradient (one more recurrent-sized product) is a hoisted GEMM over all frames
+    dense = N * (hoisted + 2 * hoisted - first + rec)
+    recurrent = N * (rec + rec)
+    return dense, recurrent
+
+
 def step_kernel_bytes(spec, B):
     """Algorithmic bytes of ONE launch of the per-timestep recurrence kernel (one timestep, both
     directions): the recurrent matrix U (or U^T) once + the per-frame activations it touches
@@ -340,10 +367,24 @@ def main():
             'roofline_step': {'bound': 'hbm', 'bytes_alg': A + W + R, 'bytes_compulsory': A + W,
                               'achieved': (A + W + R) / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                               'frac': (A + W + R) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            'roofline_mfma': None,
             'phases_ms': {k: round(v, 4) for k, v in phases.items() if k.endswith('_ms')},
             'incl_h2d': {'ms_per_step': dt_h2d * 1e3, 'value': float(frames) * world / dt_h2d, 'unit': 'frames/s',
                          'note': 'features uploaded from host memory every step (PCIe-inclusive); rank-0 clock'},
         }
+        # (ii) of SURVEY.md §8d: the dense contractions (everything hoisted out of the time loop) against the fp32 matrix
+        # peak the reference's arithmetic type would be held to; the phases include the plane / scale passes of the GEMMs
+        gf_dense, gf_rec = algorithmic_flops(spec, B, T)
+        t_dense = (phases['xproj_ms'] + phases['wgrad_ms'] + phases['proj_bwd_ms']) * 1e-3
+        out['roofline_mfma'] = {'bound': 'mfma', 'flops_alg': gf_dense, 'achieved': gf_dense / t_dense / 1e12,
+                                'peak': 157.3, 'unit': 'TFLOP/s', 'frac': gf_dense / t_dense / 1e12 / 157.3,
+                                'note': 'hoisted GEMMs (input projections, input / weight / recurrent-weight gradients, dense '
+                                        'stages, projection backward) over the xproj + wgrad + proj_bwd phases; peak = fp32 '
+                                        'MFMA (v_mfma_f32_32x32x2_f32); the GEMMs run fp32-accurate products on the 16-bit '
+                                        'matrix cores, which is how frac can exceed 1',
+                                'recurrent_flops': gf_rec,
+                                'recurrent_step_us': {'fwd': fwd_us / spl, 'bwd': bwd_us / spl,
+                                                      'dependent_launch_floor_us': 1.55}}
         if dt_ctx is not None:
             out['incl_h2d']['context_upload'] = {
                 'ms_per_step': dt_ctx * 1e3, 'value': float(frames) * world / dt_ctx,
