@@ -97,18 +97,22 @@ void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, 
 }
 
 // ------------------------------------------------------------------ (2) alpha / beta
-// workspace layout: alpha[b][t][i][lane] with state s = lane*KS + i, Tws = T + 4 rows per utterance.
+// workspace layout: alpha[b][t][i][lane] with state s = lane*KS + i, Tws = T + 8 rows per utterance.
 // The stored columns are RESCALED: alpha~(t,.) = alpha(t,.) - aoff[t], the offset (fp64, cumulative) being
 // bumped by the column maximum every 4 frames.  Raw fp32 log-domain values reach |1500| at T = 500, where one
 // ulp is 1.2e-4 and alpha+beta-logp (the posterior exponent) loses 3 digits; rescaled columns stay O(10).
 // The time loop runs in branch-free groups of 4 frames (loads clamped, updates selected) so the emission
 // gathers of the NEXT group are in flight behind counted waits while this group computes.
+#ifndef NASR_CTC_GROUP
+#define NASR_CTC_GROUP 4   // 8 (twice the prefetch distance, rescale every 8 frames): same time - the lattice is not waiting for its emissions
+#endif
 template <int KS, bool DPP>
 __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     const float* __restrict__ logits, const float* __restrict__ logz, const int* __restrict__ labels,
     const int* __restrict__ label_len, const int* __restrict__ seq_len, float* __restrict__ alpha,
     float* __restrict__ beta, double* __restrict__ aoff, double* __restrict__ boff, float* __restrict__ nll,
     double* __restrict__ logp_out, int Bp, int Cp, int C, int Lmax, int Tws) {
+  constexpr int G = NASR_CTC_GROUP;          // frames per branch-free group = prefetch distance of the emissions
   __shared__ float fin[64 * KS];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
       const int e2 = (s >= 2 && (s & 1)) ? lab[(s >> 1) - 1] : blank;   // l'_{s-2}
       skip[i] = act[i] && s >= 2 && ext[i] != blank && ext[i] != e2;
     }
-    float a[KS], e[4][KS];
+    float a[KS], e[G][KS];
     double A = 0.0;
     emit(0, e[0]);
 #pragma unroll
@@ -187,14 +191,14 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     }
     store(0, a, A);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) emit(min(1 + k, Tb - 1), e[k]);
-    for (int t0 = 1; t0 < Tb; t0 += 4) {
-      float vn[4][KS], zn[4];
+    for (int k = 0; k < G; ++k) emit(min(1 + k, Tb - 1), e[k]);
+    for (int t0 = 1; t0 < Tb; t0 += G) {
+      float vn[G][KS], zn[G];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) emit_raw(min(t0 + 4 + k, Tb - 1), vn[k], zn[k]);
+      for (int k = 0; k < G; ++k) emit_raw(min(t0 + G + k, Tb - 1), vn[k], zn[k]);
       renorm(a, A);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < G; ++k) {
         const int t = t0 + k;
         const bool live = t < Tb;
         float p1 = lane_up1<DPP>(a[KS - 1], NEG);
@@ -209,11 +213,11 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
         }
 #pragma unroll
         for (int i = 0; i < KS; ++i) a[i] = live ? (act[i] ? na[i] : NEG) : a[i];
-        store(t, a, A);              // rows Tb..Tb+2 of the workspace take dead copies (Tws = T+4)
+        store(t, a, A);              // rows Tb .. Tb+G-2 of the workspace take dead copies (Tws = T+8)
       }
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < 4; ++k) emit_finish(vn[k], zn[k], e[k]);
+      for (int k = 0; k < G; ++k) emit_finish(vn[k], zn[k], e[k]);
     }
 #pragma unroll
     for (int i = 0; i < KS; ++i) fin[lane * KS + i] = a[i];
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
       const int e2 = (s + 2 < S && (s & 1)) ? lab[(s >> 1) + 1] : blank;   // l'_{s+2}
       skip[i] = (s + 2 < S) && e2 != blank && e2 != ext[i];
     }
-    float bt[KS], e[4][KS];
+    float bt[KS], e[G][KS];
     double Bo = 0.0;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
@@ -243,14 +247,14 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     store(Tb - 1, bt, Bo);
     // e[k] holds the emission of frame (t+1) for the k-th step of a group
 #pragma unroll
-    for (int k = 0; k < 4; ++k) emit(max(Tb - 1 - k, 0), e[k]);
-    for (int t0 = Tb - 2; t0 >= 0; t0 -= 4) {
-      float vn[4][KS], zn[4];
+    for (int k = 0; k < G; ++k) emit(max(Tb - 1 - k, 0), e[k]);
+    for (int t0 = Tb - 2; t0 >= 0; t0 -= G) {
+      float vn[G][KS], zn[G];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) emit_raw(max(t0 - 4 - k + 1, 0), vn[k], zn[k]);
+      for (int k = 0; k < G; ++k) emit_raw(max(t0 - G - k + 1, 0), vn[k], zn[k]);
       renorm(bt, Bo);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < G; ++k) {
         const int t = t0 - k;
         const bool live = t >= 0;
         float bb[KS];
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
       }
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < 4; ++k) emit_finish(vn[k], zn[k], e[k]);
+      for (int k = 0; k < G; ++k) emit_finish(vn[k], zn[k], e[k]);
     }
   }
 }

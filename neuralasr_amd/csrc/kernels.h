@@ -174,7 +174,7 @@ struct CtcDims {
   int Tp;      // logit frames T'
   int B, Bp, C, Cp, Lmax;
   int KS;      // states per lane: ceil((2*Lmax+1)/64)
-  int Tws;     // rows of the alpha/beta workspace per utterance (T + 4)
+  int Tws;     // rows of the alpha/beta workspace per utterance (T + 8: a group of up to 8 frames may run past the last one)
 };
 void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, float* logz, hipStream_t st);
 void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,

@@ -582,10 +582,10 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
   const int KSa = KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations
-  ok &= h->alpha.ensure((size_t)B * (T + 4) * KSa * 64 * 4, &grew);
-  ok &= h->beta.ensure((size_t)B * (T + 4) * KSa * 64 * 4, &grew);
-  ok &= h->aoff.ensure((size_t)B * (T + 4) * 8, &grew);
-  ok &= h->boff.ensure((size_t)B * (T + 4) * 8, &grew);
+  ok &= h->alpha.ensure((size_t)B * (T + 8) * KSa * 64 * 4, &grew);
+  ok &= h->beta.ensure((size_t)B * (T + 8) * KSa * 64 * 4, &grew);
+  ok &= h->aoff.ensure((size_t)B * (T + 8) * 8, &grew);
+  ok &= h->boff.ensure((size_t)B * (T + 8) * 8, &grew);
   ok &= h->logp.ensure((size_t)Bp * 8, &grew);
   ok &= h->nll.ensure((size_t)Bp * 4, &grew);
   ok &= h->loss.ensure(16, &grew);
@@ -1014,7 +1014,7 @@ int forward(nasr_ctx* h) {
 CtcDims ctc_dims(nasr_ctx* h) {
   CtcDims d;
   d.Tp = h->Tp; d.B = h->B; d.Bp = h->Bp; d.C = h->C; d.Cp = h->Cp; d.Lmax = std::max(h->Lmax, 1);
-  d.KS = h->KS; d.Tws = h->T + 4;
+  d.KS = h->KS; d.Tws = h->T + 8;
   return d;
 }
 
