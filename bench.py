@@ -211,10 +211,14 @@ def main():
     gt = eng.grad_tensor() if use_dist else None
 
     reducer = None
-    if use_dist:
-        from neuralasr_amd.parallel import BucketedAllReduce
-        reducer = BucketedAllReduce(eng, dist, gt)
-    ar_mode = 'single' if (args.allreduce == 'single' or world == 1 or len(eng.grad_buckets()) == 1) else 'bucketed'
+    if use_dist and world > 1 and args.allreduce != 'single':
+        try:                                  # the same code on every rank: a failure here is a failure everywhere
+            from neuralasr_amd.parallel import BucketedAllReduce
+            reducer = BucketedAllReduce(eng, dist, gt)
+        except Exception as exc:              # noqa: BLE001 - fall back to the one-collective exchange
+            print(f'bucketed all-reduce unavailable ({type(exc).__name__}: {exc}); using one all-reduce', file=sys.stderr)
+            reducer = None
+    ar_mode = 'bucketed' if (reducer is not None and len(reducer.views) > 1) else 'single'
 
     def step():
         eng.compute_grads()
