@@ -53,3 +53,46 @@ def test_product_package_never_imports_the_oracle():
                 assert not py_use.search(open(src_path).read()), f'{f} imports the oracle'
             elif f.endswith(('.hip', '.h', '.cpp')):
                 assert not c_use.search(open(src_path).read()), f'{f} includes oracle code'
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/nasr.h compiles as C99, the struct layouts a C caller sees are the ones the ctypes binding assumes, and a C
+    program linked against libnasr.so gets an error code (not a crash) from nasr_create when no GPU is usable."""
+    import shutil
+    import subprocess
+    from neuralasr_amd import _lib
+    gcc = shutil.which('gcc')
+    if not gcc:
+        pytest.skip('no gcc')
+    src = tmp_path / 'abi.c'
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "nasr.h"
+int main(void) {
+  nasr_model_cfg cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.feature_size = 8; cfg.hidden = 16; cfg.num_layers = 1; cfg.bidirectional = 1; cfg.merge = NASR_MERGE_STACK_RESHAPE;
+  cfg.num_classes = 5; cfg.forget_bias = 1.0f; cfg.learning_rate = 1e-3f; cfg.beta1 = 0.9f; cfg.beta2 = 0.999f; cfg.epsilon = 1e-8f;
+  nasr_handle h = 0;
+  int rc = nasr_create(&cfg, 0, 0, &h);
+  printf("%zu %zu %d %d\n", sizeof(nasr_model_cfg), sizeof(nasr_phase_times), rc, h != 0);
+  if (h) nasr_destroy(h);
+  return 0;
+}
+''')
+    exe = tmp_path / 'abi'
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [gcc, '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe),
+           '-L', libdir, '-l:libnasr.so', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cfg_size, pt_size, rc, has_handle = (int(x) for x in out.stdout.split())
+    assert cfg_size == ctypes.sizeof(_lib.ModelCfg) and pt_size == ctypes.sizeof(_lib.PhaseTimes)
+    import torch
+    if not torch.cuda.is_available():
+        assert rc != 0 and not has_handle          # NASR_ERR_HIP: no device, no CPU fallback
+    else:
+        assert rc == 0 and has_handle
