@@ -13,7 +13,27 @@ MERGE = {'none': 0, 'stack_reshape': 1, 'concat': 2}
 class Spec(ctypes.Structure):
     _fields_ = [('feature_size', ctypes.c_int32), ('hidden', ctypes.c_int32), ('num_layers', ctypes.c_int32),
                 ('bidirectional', ctypes.c_int32), ('merge', ctypes.c_int32), ('num_classes', ctypes.c_int32),
-                ('forget_bias', ctypes.c_float)]
+                ('forget_bias', ctypes.c_float),
+                # DeepSpeech family (networks/deepspeech.py): dense stages around the stack, hash-defined dropout
+                ('num_pre', ctypes.c_int32), ('pre_width', ctypes.c_int32 * 3), ('post_width', ctypes.c_int32),
+                ('relu_clip', ctypes.c_float), ('dropout', ctypes.c_float * 4), ('drop_seed', ctypes.c_uint32),
+                ('drop_counter', ctypes.c_uint32), ('use_dropout', ctypes.c_int32)]
+
+
+def c_spec(spec, drop=None):
+    cs = Spec(spec.feature_size, spec.hidden, spec.num_layers, int(spec.bidirectional), MERGE[spec.merge],
+              spec.num_classes, float(spec.forget_bias))
+    pre = tuple(getattr(spec, 'pre', ()) or ())
+    cs.num_pre = len(pre)
+    for i, w in enumerate(pre):
+        cs.pre_width[i] = int(w)
+    cs.post_width = int(getattr(spec, 'post', 0) or 0)
+    cs.relu_clip = float(getattr(spec, 'relu_clip', 20.0))
+    if drop is not None and (pre or cs.post_width):
+        for i in range(4):
+            cs.dropout[i] = float(spec.drop_p(i))
+        cs.drop_seed, cs.drop_counter, cs.use_dropout = int(drop[0]) & 0xFFFFFFFF, int(drop[1]) & 0xFFFFFFFF, 1
+    return cs
 
 
 _lib = None
@@ -57,11 +77,11 @@ def num_threads():
     return int(load().cref_num_threads())
 
 
-def loss_and_grads(spec, flat_params, feats, seq_len, labels, label_len, want_grads=True, want_logits=False):
-    """spec: oracle.nasr_oracle.ModelSpec.  Returns (loss, nll [B], grads flat | None, logits [T',B,C] | None)."""
+def loss_and_grads(spec, flat_params, feats, seq_len, labels, label_len, want_grads=True, want_logits=False, drop=None):
+    """spec: oracle.nasr_oracle.ModelSpec; drop = (seed, counter) of the dropout masks of the DeepSpeech family, or None
+    for no dropout.  Returns (loss, nll [B], grads flat | None, logits [T',B,C] | None)."""
     lib = load()
-    cs = Spec(spec.feature_size, spec.hidden, spec.num_layers, int(spec.bidirectional), MERGE[spec.merge],
-              spec.num_classes, float(spec.forget_bias))
+    cs = c_spec(spec, drop)
     P = np.ascontiguousarray(flat_params, np.float32)
     assert P.size == lib.cref_param_count(ctypes.byref(cs))
     X = np.ascontiguousarray(feats, np.float32)

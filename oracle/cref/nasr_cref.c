@@ -8,12 +8,15 @@
  * Reference call sites followed (relative to /root/reference):
  *   networks/bilstm_ctc_net.py:17-48   BasicLSTMCell x2 in bidirectional_dynamic_rnn, stack-reshape, W/b, [2T,B,C]
  *   networks/lstm_ctc_net.py:17-43     MultiRNNCell of LSTMCell, dynamic_rnn
+ *   networks/deepspeech.py:35-127      clipped-ReLU dense stages with dropout around the (Bi)LSTM (num_pre / post_width)
  *   networks/tfnetwork.py:58-59        tf.nn.ctc_loss + reduce_mean
  * TF op semantics: SURVEY.md Appendix A.1-A.4 (gate order i,j,f,o; forget_bias inside the sigmoid; zero output and
  * carried state past seq_len; bw direction over reverse_sequence; blank = C-1; beta excludes the emission at t).
  *
  * Parameter / gradient vectors use TF variable order: per layer (fw kernel [I+H,4H], fw bias [4H], bw kernel,
- * bw bias) or (kernel, bias); then W [Hin,C], b [C].
+ * bw bias) or (kernel, bias); then W [Hin,C], b [C].  DeepSpeech family (creation order of networks/deepspeech.py):
+ * b1,h1,b2,h2,b3,h3, the cells, b5,h5, b6,h6.  Its dropout masks are the counter hash of oracle/nasr_oracle.py
+ * (dropout_mask): element idx = row*W + j of stage `layer` is kept iff lowbias32(idx ^ key) >> 8 >= floor(p * 2^24).
  */
 #include <math.h>
 #include <stdint.h>
@@ -27,7 +30,53 @@ typedef struct {
   int32_t feature_size, hidden, num_layers, bidirectional, merge; /* merge: 0 none, 1 stack_reshape, 2 concat */
   int32_t num_classes;
   float forget_bias;
+  /* DeepSpeech family; all zero for the plain (Bi)LSTM-CTC nets */
+  int32_t num_pre, pre_width[3], post_width;
+  float relu_clip, dropout[4];
+  uint32_t drop_seed, drop_counter;
+  int32_t use_dropout;
 } cref_spec;
+
+static inline int drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
+  uint32_t x = idx ^ key;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return (x >> 8) >= thr;
+}
+static inline uint32_t drop_key(const cref_spec* sp, int layer) {
+  return sp->drop_seed + 0x9E3779B9u * (uint32_t)(layer + 1) + 0x85EBCA6Bu * sp->drop_counter;
+}
+/* Y = dropout(min(relu(Z), clip)) in place on a copy: Z [R][W] -> Y [R][W] */
+static void dense_act(const cref_spec* sp, int layer, const float* Z, float* Y, size_t R, int W) {
+  const float p = sp->use_dropout ? sp->dropout[layer] : 0.f, clip = sp->relu_clip;
+  const uint32_t key = drop_key(sp, layer), thr = (uint32_t)floor((double)p * 16777216.0);
+  const float inv = 1.f / (1.f - p);
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < R; ++r)
+    for (int j = 0; j < W; ++j) {
+      float a = Z[r * W + j];
+      a = a > 0.f ? (a < clip ? a : clip) : 0.f;
+      if (p > 0.f) a = drop_keep((uint32_t)(r * W + j), key, thr) ? a * inv : 0.f;
+      Y[r * W + j] = a;
+    }
+}
+/* dZ = dY * keep/(1-p) * [0 < Z < clip], in place on dY */
+static void dense_act_bwd(const cref_spec* sp, int layer, const float* Z, float* dY, size_t R, int W) {
+  const float p = sp->use_dropout ? sp->dropout[layer] : 0.f, clip = sp->relu_clip;
+  const uint32_t key = drop_key(sp, layer), thr = (uint32_t)floor((double)p * 16777216.0);
+  const float inv = 1.f / (1.f - p);
+#pragma omp parallel for schedule(static)
+  for (size_t r = 0; r < R; ++r)
+    for (int j = 0; j < W; ++j) {
+      const float z = Z[r * W + j];
+      float g = (z > 0.f && z < clip) ? dY[r * W + j] : 0.f;
+      if (p > 0.f) g = drop_keep((uint32_t)(r * W + j), key, thr) ? g * inv : 0.f;
+      dY[r * W + j] = g;
+    }
+}
+static void colsum(const float* M, size_t R, int W, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < W; ++j) { double s = 0; for (size_t r = 0; r < R; ++r) s += M[r * W + j]; out[j] = (float)s; }
+}
 
 static inline float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -250,12 +299,17 @@ static double ctc_one(const float* lg, size_t ls, int Tb, int C, const int32_t* 
 int64_t cref_param_count(const cref_spec* sp) {
   const int D = sp->bidirectional ? 2 : 1, H = sp->hidden;
   int64_t n = 0;
+  const int F0c = sp->num_pre ? sp->pre_width[sp->num_pre - 1] : sp->feature_size;
   for (int l = 0; l < sp->num_layers; ++l) {
-    const int I = l == 0 ? sp->feature_size : D * H;
+    const int I = l == 0 ? F0c : D * H;
     n += (int64_t)D * ((int64_t)(I + H) * 4 * H + 4 * H);
   }
   const int Pin = (sp->bidirectional && sp->merge == 2) ? 2 * H : H;
-  return n + (int64_t)Pin * sp->num_classes + sp->num_classes;
+  for (int i = 0; i < sp->num_pre; ++i)
+    n += (int64_t)(i == 0 ? sp->feature_size : sp->pre_width[i - 1]) * sp->pre_width[i] + sp->pre_width[i];
+  if (sp->post_width) n += (int64_t)Pin * sp->post_width + sp->post_width;
+  const int Pp = sp->post_width ? sp->post_width : Pin;
+  return n + (int64_t)Pp * sp->num_classes + sp->num_classes;
 }
 
 void cref_set_threads(int n) {
@@ -290,12 +344,21 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
     if (label_len[b] + rep > seq_len[b]) return -3;
   }
   /* ---- parameter views */
+  const int npre = sp->num_pre, post = sp->post_width;
+  const int F0 = npre ? sp->pre_width[npre - 1] : F;   /* width the first LSTM layer reads */
   dir_t* dirs = (dir_t*)calloc((size_t)L * D, sizeof(dir_t));
   const float* p = params;
+  const float *pb[3] = {0, 0, 0}, *ph[3] = {0, 0, 0};
+  int pin_w[3] = {0, 0, 0};
+  for (int i = 0; i < npre; ++i) {
+    pin_w[i] = i == 0 ? F : sp->pre_width[i - 1];
+    pb[i] = p; p += sp->pre_width[i];
+    ph[i] = p; p += (size_t)pin_w[i] * sp->pre_width[i];
+  }
   for (int l = 0; l < L; ++l)
     for (int d = 0; d < D; ++d) {
       dir_t* q = &dirs[l * D + d];
-      q->I = l == 0 ? F : D * H; q->H = H;
+      q->I = l == 0 ? F0 : D * H; q->H = H;
       q->kernel = p; p += (size_t)(q->I + H) * 4 * H;
       q->bias = p; p += 4 * H;
       q->xp = (float*)malloc(R * 4 * H * sizeof(float));
@@ -303,14 +366,28 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
       q->c = (float*)malloc(R * H * sizeof(float));
       q->out = (float*)malloc(R * H * sizeof(float));
     }
-  const float* W = p; p += (size_t)Pin * C;
-  const float* bproj = p;
+  const float *b5 = 0, *h5 = 0;
+  if (post) { b5 = p; p += post; h5 = p; p += (size_t)Pin * post; }
+  const int Pp = post ? post : Pin;                    /* width the projection reads */
+  const float *W, *bproj;
+  if (npre || post) { bproj = p; p += C; W = p; }      /* b6, h6 */
+  else { W = p; p += (size_t)Pin * C; bproj = p; }
   /* ---- forward */
   float** X = (float**)calloc((size_t)L + 1, sizeof(float*));
-  X[0] = (float*)malloc(R * F * sizeof(float));
+  float* feat_tm = (float*)malloc(R * F * sizeof(float));
 #pragma omp parallel for
   for (int t = 0; t < T; ++t)
-    for (int b = 0; b < B; ++b) memcpy(X[0] + ((size_t)t * B + b) * F, feats + ((size_t)b * T + t) * F, (size_t)F * sizeof(float));
+    for (int b = 0; b < B; ++b) memcpy(feat_tm + ((size_t)t * B + b) * F, feats + ((size_t)b * T + t) * F, (size_t)F * sizeof(float));
+  /* dense stages in front of the stack: Zpre[i] pre-activations, Ypre[i] outputs */
+  float *Zpre[3] = {0, 0, 0}, *Ypre[3] = {0, 0, 0};
+  for (int i = 0; i < npre; ++i) {
+    const int Wd = sp->pre_width[i];
+    Zpre[i] = (float*)malloc(R * Wd * sizeof(float));
+    Ypre[i] = (float*)malloc(R * Wd * sizeof(float));
+    gemm_nn(i == 0 ? feat_tm : Ypre[i - 1], ph[i], Zpre[i], (int)R, Wd, pin_w[i], pin_w[i], Wd, Wd, pb[i]);
+    dense_act(sp, i, Zpre[i], Ypre[i], R, Wd);
+  }
+  X[0] = npre ? Ypre[npre - 1] : feat_tm;
   for (int l = 0; l < L; ++l) {
     for (int d = 0; d < D; ++d) lstm_dir_forward(&dirs[l * D + d], X[l], seq_len, B, T, d == 1, sp->forget_bias);
     X[l + 1] = (float*)malloc(R * D * H * sizeof(float));
@@ -334,8 +411,16 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
       memcpy(flat + rr * Pin, X[L] + rr * Pin, (size_t)Pin * sizeof(float));
     }
   }
+  float *Zpost = 0, *Ypost = 0;
+  if (post) {
+    Zpost = (float*)malloc(Rp * post * sizeof(float));
+    Ypost = (float*)malloc(Rp * post * sizeof(float));
+    gemm_nn(flat, h5, Zpost, (int)Rp, post, Pin, Pin, post, post, b5);
+    dense_act(sp, npre, Zpost, Ypost, Rp, post);
+  }
+  const float* proj_in = post ? Ypost : flat;
   float* logits = (float*)malloc(Rp * C * sizeof(float));
-  gemm_nn(flat, W, logits, (int)Rp, C, Pin, Pin, C, C, bproj);
+  gemm_nn(proj_in, W, logits, (int)Rp, C, Pp, Pp, C, C, bproj);
   if (logits_out) memcpy(logits_out, logits, Rp * C * sizeof(float));
   /* ---- CTC */
   float* dlog = (float*)calloc(Rp * C, sizeof(float));
@@ -349,6 +434,8 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
   if (loss_out) *loss_out = (float)(total / B);
   if (grads) {
     float* g = grads;
+    float *gpb[3] = {0, 0, 0}, *gph[3] = {0, 0, 0};
+    for (int i = 0; i < npre; ++i) { gpb[i] = g; g += sp->pre_width[i]; gph[i] = g; g += (size_t)pin_w[i] * sp->pre_width[i]; }
     float** gk = (float**)calloc((size_t)L * D, sizeof(float*));
     float** gb = (float**)calloc((size_t)L * D, sizeof(float*));
     for (int l = 0; l < L; ++l)
@@ -356,12 +443,25 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
         gk[l * D + d] = g; g += (size_t)(dirs[l * D + d].I + H) * 4 * H;
         gb[l * D + d] = g; g += 4 * H;
       }
-    float* gW = g; g += (size_t)Pin * C;
-    float* gbp = g;
-    gemm_tn(flat, dlog, gW, Pin, C, (int)Rp, Pin, C, C);
-    for (int c = 0; c < C; ++c) { double s = 0; for (size_t rr = 0; rr < Rp; ++rr) s += dlog[rr * C + c]; gbp[c] = (float)s; }
+    float *gb5 = 0, *gh5 = 0;
+    if (post) { gb5 = g; g += post; gh5 = g; g += (size_t)Pin * post; }
+    float *gW, *gbp;
+    if (npre || post) { gbp = g; g += C; gW = g; }
+    else { gW = g; g += (size_t)Pin * C; gbp = g; }
+    gemm_tn(proj_in, dlog, gW, Pp, C, (int)Rp, Pp, C, C);
+    colsum(dlog, Rp, C, gbp);
     float* dflat = (float*)malloc(Rp * Pin * sizeof(float));
-    gemm_nt(dlog, W, dflat, (int)Rp, Pin, C, C, C, Pin, 0);
+    if (post) {
+      float* dYp = (float*)malloc(Rp * post * sizeof(float));
+      gemm_nt(dlog, W, dYp, (int)Rp, post, C, C, C, post, 0);
+      dense_act_bwd(sp, npre, Zpost, dYp, Rp, post);            /* dYp is dZ5 now */
+      gemm_tn(flat, dYp, gh5, Pin, post, (int)Rp, Pin, post, post);
+      colsum(dYp, Rp, post, gb5);
+      gemm_nt(dYp, h5, dflat, (int)Rp, Pin, post, post, post, Pin, 0);
+      free(dYp);
+    } else {
+      gemm_nt(dlog, W, dflat, (int)Rp, Pin, C, C, C, Pin, 0);
+    }
     /* gradient wrt the last layer's outputs, per direction [T*B][H] */
     float** dout = (float**)calloc((size_t)D, sizeof(float*));
     for (int d = 0; d < D; ++d) dout[d] = (float*)calloc(R * H, sizeof(float));
@@ -382,7 +482,7 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
     float* hprev = (float*)malloc(R * H * sizeof(float));
     for (int l = L - 1; l >= 0; --l) {
       const int I = dirs[l * D].I;
-      float* dX = l > 0 ? (float*)calloc(R * I, sizeof(float)) : NULL;
+      float* dX = (l > 0 || npre) ? (float*)calloc(R * I, sizeof(float)) : NULL;
       for (int d = 0; d < D; ++d) {
         dir_t* q = &dirs[l * D + d];
         lstm_dir_backward(q, dout[d], dG, seq_len, B, T, d == 1);
@@ -393,13 +493,29 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
         else memcpy(hprev, q->out + (size_t)B * H, (R - B) * H * sizeof(float));
         gemm_tn(hprev, dG, gk[l * D + d] + (size_t)I * 4 * H, H, 4 * H, (int)R, H, 4 * H, 4 * H);
         for (int n = 0; n < 4 * H; ++n) { double s = 0; for (size_t r = 0; r < R; ++r) s += dG[r * 4 * H + n]; gb[l * D + d][n] = (float)s; }
-        if (l > 0) gemm_nt(dG, q->kernel, dX, (int)R, I, 4 * H, 4 * H, 4 * H, I, 1);   /* rows 0..I-1 of kernel = Wx */
+        if (dX) gemm_nt(dG, q->kernel, dX, (int)R, I, 4 * H, 4 * H, 4 * H, I, 1);   /* rows 0..I-1 of kernel = Wx */
       }
       if (l > 0) {
         for (int d = 0; d < D; ++d)
 #pragma omp parallel for
           for (size_t r = 0; r < R; ++r) memcpy(dout[d] + r * H, dX + r * I + (size_t)d * H, (size_t)H * sizeof(float));
         free(dX);
+      } else if (npre) {
+        /* dense stages in front of the stack, last to first: dX is d loss / d Ypre[npre-1] */
+        float* dY = dX;
+        for (int i = npre - 1; i >= 0; --i) {
+          const int Wd = sp->pre_width[i];
+          dense_act_bwd(sp, i, Zpre[i], dY, R, Wd);
+          gemm_tn(i == 0 ? feat_tm : Ypre[i - 1], dY, gph[i], pin_w[i], Wd, (int)R, pin_w[i], Wd, Wd);
+          colsum(dY, R, Wd, gpb[i]);
+          float* dIn = NULL;
+          if (i > 0) {
+            dIn = (float*)malloc(R * pin_w[i] * sizeof(float));
+            gemm_nt(dY, ph[i], dIn, (int)R, pin_w[i], Wd, Wd, Wd, pin_w[i], 0);
+          }
+          free(dY);
+          dY = dIn;
+        }
       }
     }
     free(dG); free(hprev); free(dflat);
@@ -407,8 +523,11 @@ int cref_loss_and_grads(const cref_spec* sp, const float* params, const float* f
     free(dout); free(gk); free(gb);
   }
   free(nlls); free(dlog); free(logits); free(flat);
-  for (int l = 0; l <= L; ++l) free(X[l]);
+  free(Zpost); free(Ypost);
+  for (int l = 1; l <= L; ++l) free(X[l]);            /* X[0] is feat_tm or the last dense output */
   free(X);
+  for (int i = 0; i < npre; ++i) { free(Zpre[i]); free(Ypre[i]); }
+  free(feat_tm);
   for (int i = 0; i < L * D; ++i) { free(dirs[i].xp); free(dirs[i].act); free(dirs[i].c); free(dirs[i].out); }
   free(dirs);
   return 0;
