@@ -20,9 +20,16 @@ namespace nasr {
 
 constexpr float NEG = -1e30f;
 
+// log(e^a + e^b + e^c).  The lattice spends 144 instructions per frame on three of these: the bare v_exp_f32 / v_log_f32
+// are used, without the denormal scaling __expf / __logf wrap around them - the arguments of exp are <= 0 (results
+// below 2^-126 may flush to zero: they vanish against the 1.0 of the maximum's own term) and the argument of log is in
+// [1, 3].
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(a, fmaxf(b, c));
-  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+  const float L2E = 1.44269504088896341f, LN2 = 0.69314718055994531f;
+  const float s = __builtin_amdgcn_exp2f((a - m) * L2E) + __builtin_amdgcn_exp2f((b - m) * L2E) +
+                  __builtin_amdgcn_exp2f((c - m) * L2E);
+  return m + __builtin_amdgcn_logf(s) * LN2;
 }
 
 // lane l <- lane l-1 / l+1 as ONE DPP move (wave_shr:1 / wave_shl:1; the first / last lane gets `edge`) instead of a
