@@ -20,6 +20,15 @@ namespace nasr {
 
 constexpr float NEG = -1e30f;
 
+// wave-uniform base + 32-bit BYTE offset: the zero-extended offset is the addressing mode's own (saddr + voffset), no
+// 64-bit arithmetic per access
+__device__ __forceinline__ float ldf(const float* base, unsigned byteoff) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byteoff);
+}
+__device__ __forceinline__ void stf(float* base, unsigned byteoff, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byteoff) = v;
+}
+
 // log(e^a + e^b + e^c).  The lattice spends 144 instructions per frame on three of these: the bare v_exp_f32 / v_log_f32
 // are used, without the denormal scaling __expf / __logf wrap around them - the arguments of exp are <= 0 (results
 // below 2^-126 may flush to zero: they vanish against the 1.0 of the maximum's own term) and the argument of log is in
@@ -135,14 +144,16 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
     act[i] = s < S;
     ext[i] = (act[i] && (s & 1)) ? lab[s >> 1] : blank;
   }
-  const size_t rstride = (size_t)Bp * Cp;               // logits row stride between frames
+  // 32-bit element offsets from wave-uniform bases (the launcher checks T' * Bp * Cp < 2^32): one v_mad_u32 per gather
+  // or store instead of 64-bit address arithmetic - the lattice is bound by its instruction count
+  const unsigned rstride = (unsigned)Bp * (unsigned)Cp;  // logits row stride between frames
   const float* lg = logits + (size_t)b * Cp;
   const float* lz = logz + b;
   auto emit = [&](int t, float (&e)[KS]) {               // t must be a valid frame (callers clamp)
-    const float z = lz[(size_t)t * Bp];
+    const float z = ldf(lz, (unsigned)t * (unsigned)Bp * 4u);
     float v[KS];
 #pragma unroll
-    for (int i = 0; i < KS; ++i) v[i] = lg[(size_t)t * rstride + ext[i]];   // unconditional: ext is always a class id
+    for (int i = 0; i < KS; ++i) v[i] = ldf(lg, ((unsigned)t * rstride + (unsigned)ext[i]) * 4u);   // unconditional: ext is always a class id
 #pragma unroll
     for (int i = 0; i < KS; ++i) e[i] = act[i] ? v[i] - z : NEG;
   };
@@ -150,9 +161,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
   // into emissions only after it.  (With `emit` hipcc computed v - z right behind the loads, i.e. waited for all 16
   // gathers of the next group at the top of every group: ~500 of the ~900 cycles a frame took.)
   auto emit_raw = [&](int t, float (&v)[KS], float& z) {
-    z = lz[(size_t)t * Bp];
+    z = ldf(lz, (unsigned)t * (unsigned)Bp * 4u);
 #pragma unroll
-    for (int i = 0; i < KS; ++i) v[i] = lg[(size_t)t * rstride + ext[i]];
+    for (int i = 0; i < KS; ++i) v[i] = ldf(lg, ((unsigned)t * rstride + (unsigned)ext[i]) * 4u);
   };
   auto emit_finish = [&](float (&v)[KS], float z, float (&e)[KS]) {
     asm volatile("" : "+v"(z));
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
   double* off = (w == 0 ? aoff : boff) + (size_t)b * Tws;
   auto store = [&](int t, const float (&a)[KS], double o) {
 #pragma unroll
-    for (int i = 0; i < KS; ++i) ws[((size_t)t * KS + i) * 64 + lane] = a[i];
+    for (int i = 0; i < KS; ++i) stf(ws, (((unsigned)t * KS + i) * 64u + (unsigned)lane) * 4u, a[i]);
     if (lane == 0) off[t] = o;
   };
   auto renorm = [&](float (&a)[KS], double& o) {
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
           na[i] = e[k][i] + lse3(a[i], x1, skip[i] ? x2 : NEG);
         }
 #pragma unroll
-        for (int i = 0; i < KS; ++i) a[i] = live ? (act[i] ? na[i] : NEG) : a[i];
+        for (int i = 0; i < KS; ++i) a[i] = live ? na[i] : a[i];   // a state past S has e = NEG: its na is ~NEG by itself
         store(t, a, A);              // rows Tb .. Tb+G-2 of the workspace take dead copies (Tws = T+8)
       }
       asm volatile("" ::: "memory");
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
         const bool live = t >= 0;
         float bb[KS];
 #pragma unroll
-        for (int i = 0; i < KS; ++i) bb[i] = act[i] ? bt[i] + e[k][i] : NEG;
+        for (int i = 0; i < KS; ++i) bb[i] = bt[i] + e[k][i];      // states past S: NEG + NEG, rescaled back to NEG every group
         float n1 = lane_down1<DPP>(bb[0], NEG);
         float n2 = (KS >= 2) ? lane_down1<DPP>(bb[KS >= 2 ? 1 : 0], NEG) : __shfl_down(bb[0], 2);
         if (KS == 1 && lane >= 62) n2 = NEG;
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(
           nb[i] = lse3(bb[i], x1, skip[i] ? x2 : NEG);
         }
 #pragma unroll
-        for (int i = 0; i < KS; ++i) bt[i] = live ? (act[i] ? nb[i] : NEG) : bt[i];
+        for (int i = 0; i < KS; ++i) bt[i] = live ? nb[i] : bt[i];
         if (live) store(t, bt, Bo);
       }
       asm volatile("" ::: "memory");
