@@ -55,8 +55,10 @@ __device__ __forceinline__ void st_state(float* p, float v) {
   *p = v;
 #endif
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+// bare v_exp_f32, as in lstm_persist.hip (saturation makes the denormal scaling of __expf pointless here)
+__device__ __forceinline__ float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + exp_(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + exp_(2.f * x)); }
 
 // Element (row b16, unit k) of M-tile mt inside the swizzled h-state image (contraction length Kd).
 // Lane l of 16-byte group q holds, in component i, the value the MFMA k-step 4q+i wants from lane l:

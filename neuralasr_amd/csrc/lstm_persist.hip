@@ -76,8 +76,13 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 typedef volatile __attribute__((address_space(3))) unsigned lds_vu32;   // a volatile access through a GENERIC pointer to LDS
                                                                         // compiles to flat_store sc0 sc1 + vmcnt(0)
 
-__device__ __forceinline__ float psig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float ptanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+// The bare v_exp_f32 (2^x), without the denormal scaling __expf can wrap around it: an exponential that overflows to inf
+// or flushes to 0 gives the saturated value of the sigmoid / tanh either way, and in the normal range the two are the
+// same instruction on the same input (results bitwise equal; measured time equal too - the cell wave's chain is latency,
+// not issue).
+__device__ __forceinline__ float pexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float psig(float x) { return __builtin_amdgcn_rcpf(1.f + pexp(-x)); }
+__device__ __forceinline__ float ptanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + pexp(2.f * x)); }
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
