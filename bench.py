@@ -183,11 +183,19 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    if os.environ.get('NASR_BENCH_BACKEND', 'nccl') != 'nccl':
+        local = 0                                   # rehearsal: every rank on the one GPU
     torch.cuda.set_device(local)
     use_dist = world > 1 or 'RANK' in os.environ        # under torch.distributed.run even at N = 1
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        # NASR_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with several ranks on ONE GPU (RCCL refuses that);
+        # never a measurement
+        backend = os.environ.get('NASR_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
 
     spec, wname = workload_spec(args.workload)
     B, T = args.batch or (32 if args.workload == 'deepspeech' else 16), args.frames
