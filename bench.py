@@ -365,6 +365,8 @@ def main():
                        'batch_per_gpu': B, 'frames': T, 'var_len': bool(args.var_len),
                        'parallelism': f'dp{world}', 'hipgraph': not args.no_graph,
                        'recurrence': eng.recurrence_mode,
+                       'recurrence_forward_mfma': ('fp32 products from 2 fp16 planes of U and 2 fp16 parts of h (4x4x4 f16 MFMA)'
+                                                   if os.environ.get('NASR_REC', 'f16') != 'f32' else 'fp32 4x4x1 MFMA'),
                        'gemm': {'tp': 'fp32 products from 2 fp16 planes x 3 MFMA products, fp32 accumulation, power-of-two '
                                       'row scales (gemm_tph.hip)',
                                 'tp3': 'fp32 products from 3 bf16 planes x 6 MFMA products, fp32 accumulation (gemm_tp.hip)',

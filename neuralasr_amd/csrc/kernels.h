@@ -153,12 +153,15 @@ size_t persist_xch_floats(int Hp);               // floats of the exchange buffe
 hipError_t persist_prepare();                    // once per process: raise the kernels' dynamic-LDS limit
 // all n (layer, direction) matrices in one launch: matrix k is P + offs[k], its images Upf + k*image_floats(fwd) / Upb + k*...(bwd)
 constexpr int PERSIST_MAX_MATS = 16;
-void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Upf, float* Upb, int Hp, hipStream_t st);
+// col_scale (or NULL): [n][4*Hp] power-of-two scales of every matrix's columns -> the forward image holds two fp16 planes
+void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Upf, float* Upb, int Hp, const float* col_scale,
+                           hipStream_t st);
 // Upf/Upb: [D] images of this layer; xch: persist_xch_floats(Hp) floats; ctl: one PersistCtl (zeroed by the launcher);
 // sticky: host-mapped word that receives the error code of an aborted launch (or NULL); fault: device float set to 1
 // by an aborted launch (or NULL) - the engine keeps it behind the gradients so that it is all-reduced with them
-void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates, float* cbuf, float* out,
-                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
+// cinv (or NULL): [D][4*Hp] inverse column scales of this layer's matrices = the fp16 form of the forward image
+void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* cinv, float* gates, float* cbuf,
+                             float* out, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
                              float forget_bias, hipStream_t st);
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,

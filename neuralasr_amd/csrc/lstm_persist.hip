@@ -140,9 +140,14 @@ __device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, fl
 //        the output unit k = w*KW + og*64 + lane (zero when og*64 + lane >= KW).
 // blockIdx.y = (layer, direction) k: its matrix starts at P + off.o[k], its images at Upf0 + k*imf / Upb0 + k*imb
 struct RepackOffs { long long o[PERSIST_MAX_MATS]; };
+// cs0 != NULL: the forward image holds TWO fp16 planes of U scaled per column (cs0 + k*N4: power-of-two scales that bring
+// each column's largest magnitude into [2^14, 2^15), gemm_tph.hip) for v_mfma_f32_4x4x4_16B_f16, same bytes:
+//   Upf as 8-byte units [32 m][4 w][KW/4 bb][2 planes][64 lane]: the 4 halfs are units k = w*KW + 4*bb + 0..3 of the
+//   lane's column; plane 0 = fp16(U*s), plane 1 = fp16(U*s - plane 0).
 __global__ __launch_bounds__(256) void repack_persist_kernel(const float* __restrict__ P, RepackOffs off,
                                                              float* __restrict__ Upf0, float* __restrict__ Upb0,
-                                                             long long imf, long long imb, int Hp) {
+                                                             long long imf, long long imb, int Hp,
+                                                             const float* __restrict__ cs0) {
   const float* __restrict__ U = P + off.o[blockIdx.y];
   float* __restrict__ Upf = Upf0 + (size_t)blockIdx.y * imf;
   float* __restrict__ Upb = Upb0 + (size_t)blockIdx.y * imb;
@@ -156,7 +161,24 @@ __global__ __launch_bounds__(256) void repack_persist_kernel(const float* __rest
       const int idx = (int)(x % KW); x /= KW;
       const int w = (int)(x & 3), m = (int)(x >> 2);
       const int bp = lane >> 2, g = lane & 3;
-      Upf[e] = bp < NU ? U[(size_t)(w * KW + idx) * N4 + 4 * (NU * m + bp) + g] : 0.f;
+      if (!cs0) {
+        Upf[e] = bp < NU ? U[(size_t)(w * KW + idx) * N4 + 4 * (NU * m + bp) + g] : 0.f;
+      } else if ((idx & 3) == 0) {       // one thread per (chunk of 4 units, lane): both planes
+        const int col = 4 * (NU * m + bp) + g;
+        const float sc = bp < NU ? cs0[(size_t)blockIdx.y * N4 + col] : 1.f;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 p1, p2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = bp < NU ? U[(size_t)(w * KW + idx + r) * N4 + col] * sc : 0.f;
+          const _Float16 h1 = (_Float16)v;
+          p1[r] = h1;
+          p2[r] = (_Float16)(v - (float)h1);
+        }
+        h4* dst = reinterpret_cast<h4*>(Upf) + ((((size_t)m * 4 + w) * (KW / 4) + idx / 4) * 2) * 64 + lane;
+        dst[0] = p1;
+        dst[64] = p2;
+      }
     } else {
       const int64_t eb = e - nf;
       const int lane = eb & 63;
@@ -175,14 +197,15 @@ size_t persist_image_floats(int Hp, bool bwd) {
   return (size_t)32 * 4 * 64 * (bwd ? NOG * 4 * NU : KW);
 }
 
-void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Upf, float* Upb, int Hp, hipStream_t st) {
+void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Upf, float* Upb, int Hp, const float* col_scale,
+                           hipStream_t st) {
   const long long imf = (long long)persist_image_floats(Hp, false), imb = (long long)persist_image_floats(Hp, true);
   for (int k0 = 0; k0 < n; k0 += PERSIST_MAX_MATS) {
     const int m = n - k0 < PERSIST_MAX_MATS ? n - k0 : PERSIST_MAX_MATS;
     RepackOffs off{};
     for (int k = 0; k < m; ++k) off.o[k] = offs[k0 + k];
     hipLaunchKernelGGL(repack_persist_kernel, dim3(512, m), dim3(256), 0, st, P, off, Upf + (size_t)k0 * imf,
-                       Upb + (size_t)k0 * imb, imf, imb, Hp);
+                       Upb + (size_t)k0 * imb, imf, imb, Hp, col_scale ? col_scale + (size_t)k0 * 4 * Hp : nullptr);
   }
 }
 
@@ -209,12 +232,16 @@ constexpr int LDS_RED = 0, LDS_ADG = 2 * 4 * 4 * 64, LDS_SIDE = LDS_ADG + 2 * 25
 // when the memory system is otherwise idle.  Measured (forward, us per step): loads and stores in the cell wave 1.69,
 // in an MFMA wave right after the publish 1.64 (they compete with the hand-off), none at all 1.46.
 
-template <int NU>
+// F16: the recurrent product runs on v_mfma_f32_4x4x4_16B_f16 - U as two fp16 planes under per-column scales (register
+// footprint unchanged), h (|h| < 1) split into two fp16 parts of h * 2^14 once per step, three MFMAs per chunk of 4 units
+// (h1 U1 + h1 U2 + h2 U1) instead of four fp32 ones: 96 instead of 128 MFMAs of the same duration per wave and step,
+// the same accuracy class as the fp16-plane GEMMs.  cinv [D][N4]: 1 / column scale.
+template <int NU, bool F16>
 __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
     const float* __restrict__ Upf,   // [D] images
     float* gates, float* cbuf, float* out, const int* __restrict__ seq_len,
     float* hx,                       // [8 groups][2 parity][Hp*4]
-    PersistCtl* ctl, unsigned* sticky, PersistGeom gm, float fb) {
+    PersistCtl* ctl, unsigned* sticky, PersistGeom gm, float fb, const float* __restrict__ cinv) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KW = 8 * NU;                 // units (= MFMAs) per wave
   constexpr int NCH = 2 * NU;                // 16-byte chunks (4 units x 1 utterance) per wave and utterance
@@ -233,11 +260,22 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
   if (w < 4) __builtin_amdgcn_s_setprio(3);
 
   // this wave's slice of the recurrent matrix, resident for the whole launch
-  float wreg[KW];
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  float wreg[F16 ? 1 : KW];
+  h4 w1[F16 ? KW / 4 : 1], w2[F16 ? KW / 4 : 1];
+  float oscale = 1.f;                               // F16: 2^-14 / column scale of this lane's output column
   if (w < 4) {
-    const float* wp = Upf + ((((size_t)d * 32 + member) * 4 + w) * KW) * 64 + lane;
+    if constexpr (F16) {
+      const h4* wp = reinterpret_cast<const h4*>(Upf) + ((((size_t)d * 32 + member) * 4 + w) * (KW / 4) * 2) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < KW; ++i) wreg[i] = wp[(size_t)i * 64];
+      for (int i = 0; i < KW / 4; ++i) { w1[i] = wp[(size_t)(2 * i) * 64]; w2[i] = wp[(size_t)(2 * i + 1) * 64]; }
+      const int bp = lane >> 2, g = lane & 3;
+      oscale = (bp < NU ? cinv[(size_t)d * 4 * gm.Hp + 4 * (NU * (int)member + bp) + g] : 1.f) * (1.f / 16384.f);
+    } else {
+      const float* wp = Upf + ((((size_t)d * 32 + member) * 4 + w) * KW) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < KW; ++i) wreg[i] = wp[(size_t)i * 64];
+    }
   }
   float* ghx = hx + (size_t)xcc * 2 * Hp * 4;
   gu32* gflag = (gu32*)(ctl->flags + xcc * 128);
@@ -323,15 +361,35 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
         stp.mark(2);
         if (s > 0 && ok) {
           // 3. acc[.][utt] (16 units x 4 gates) += h[utt][k] * U[k][cols]; A broadcast from block bb%16
-          static_for<0, NCH>([&](auto bbc) {
-            constexpr int bb = decltype(bbc)::value;
-            static_for<0, 4>([&](auto rc) {
-              constexpr int r = decltype(rc)::value;
-              acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[bb / 16][r], wreg[bb * 4 + r], acc[r], 4, bb % 16, 0);
+          if constexpr (F16) {
+            h4 a1[NJ], a2[NJ];
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = P[i][r] * 16384.f;
+                const _Float16 h1 = (_Float16)v;
+                a1[i][r] = h1;
+                a2[i][r] = (_Float16)(v - (float)h1);
+              }
+            static_for<0, NCH>([&](auto bbc) {
+              constexpr int bb = decltype(bbc)::value;
+              acc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a2[bb / 16], w1[bb], acc[0], 4, bb % 16, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1[bb / 16], w2[bb], acc[1], 4, bb % 16, 0);
+              acc[2] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1[bb / 16], w1[bb], acc[2], 4, bb % 16, 0);
             });
-          });
+          } else {
+            static_for<0, NCH>([&](auto bbc) {
+              constexpr int bb = decltype(bbc)::value;
+              static_for<0, 4>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                acc[r] = __builtin_amdgcn_mfma_f32_4x4x1f32(P[bb / 16][r], wreg[bb * 4 + r], acc[r], 4, bb % 16, 0);
+              });
+            });
+          }
         }
-        const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if constexpr (F16) sum *= oscale;
         float* rw = red + ((par * 4 + w) * 4) * 64 + lane;
         rw[0] = sum[0]; rw[64] = sum[1]; rw[128] = sum[2]; rw[192] = sum[3];
         if (!ok) info[2 + par] = 1;
@@ -638,7 +696,10 @@ hipError_t persist_prepare() {
   hipError_t e = hipSuccess;
 #define NASR_PATTR(NUV)                                                                                             \
   if (e == hipSuccess)                                                                                              \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_fwd_kernel<NUV>),                           \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_fwd_kernel<NUV, false>),                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS_BYTES);                         \
+  if (e == hipSuccess)                                                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_fwd_kernel<NUV, true>),                     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS_BYTES);                         \
   if (e == hipSuccess)                                                                                              \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_persist_bwd_kernel<NUV>),                           \
@@ -648,16 +709,20 @@ hipError_t persist_prepare() {
   return e;
 }
 
-void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, float* gates, float* cbuf, float* out,
-                             const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
+void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* cinv, float* gates, float* cbuf,
+                             float* out, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
                              float forget_bias, hipStream_t st) {
   PersistGeom gm = make_geom(dm);
   gm.fault = fault;
   (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(320);
 #define NASR_PF(NUV)                                                                                                  \
-  hipLaunchKernelGGL((lstm_persist_fwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upf, gates, cbuf, out, seq_len, \
-                     xch, ctl, sticky, gm, forget_bias)
+  if (cinv)                                                                                                           \
+    hipLaunchKernelGGL((lstm_persist_fwd_kernel<NUV, true>), grid, block, PERSIST_LDS_BYTES, st, Upf, gates, cbuf, out,   \
+                       seq_len, xch, ctl, sticky, gm, forget_bias, cinv);                                               \
+  else                                                                                                                \
+    hipLaunchKernelGGL((lstm_persist_fwd_kernel<NUV, false>), grid, block, PERSIST_LDS_BYTES, st, Upf, gates, cbuf, out,  \
+                       seq_len, xch, ctl, sticky, gm, forget_bias, cinv)
   switch (dm.Hp / 32) {
     case 2: NASR_PF(2); break;
     case 4: NASR_PF(4); break;

@@ -98,6 +98,10 @@ struct nasr_ctx {
   bool persist_used = false;           // a persistent launch is in flight since the last check of *perr
   int adam_unverified = 0;             // Adam launches since the last check of the step's fault word
   float *Upf = nullptr, *Upb = nullptr;   // [L][D] operand images
+  // forward recurrence on fp16 planes of U (v_mfma_f32_4x4x4_16B_f16, lstm_persist.hip): column scales / inverse scales of
+  // every (layer, direction) matrix, [L*D][N4] each, measured after every optimiser step.  NASR_REC=f32 keeps fp32 MFMAs.
+  bool rec_f16 = false;
+  float *Ucs = nullptr, *Ucinv = nullptr;
   size_t imf = 0, imb = 0;             // floats per (layer, direction) image
   float* xch = nullptr;                // exchange buffer
   PersistCtl* pctl = nullptr;
@@ -466,7 +470,14 @@ int build_layout(nasr_ctx* h) {
 int repack(nasr_ctx* h) {
   // only the operand images of the kernels in use (a mode switch calls repack again)
   if (h->persist) {
-    launch_repack_persist(h->P, h->off_u.data(), (int)h->off_u.size(), h->Upf, h->Upb, h->Hp, h->st);
+    if (h->rec_f16) {   // column scales of every recurrent matrix (two launches), then the fp16 forward image
+      std::vector<TphScaleJob> jobs;
+      for (size_t k = 0; k < h->off_u.size(); ++k)
+        jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, nullptr, nullptr, h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
+      launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
+    }
+    launch_repack_persist(h->P, h->off_u.data(), (int)h->off_u.size(), h->Upf, h->Upb, h->Hp,
+                          h->rec_f16 ? h->Ucs : nullptr, h->st);
   } else {
     for (int l = 0; l < h->L; ++l)
       for (int d = 0; d < h->D; ++d) {
@@ -734,7 +745,8 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
   if (h->persist && s0 == 0 && s1 == h->T) {
     const size_t k = (size_t)l * h->D;
     if (!bwd)
-      launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->gates[l].as<float>(), h->cbuf[l].as<float>(),
+      launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->rec_f16 ? h->Ucinv + k * h->N4 : nullptr,
+                              h->gates[l].as<float>(), h->cbuf[l].as<float>(),
                               h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->Gbase,
                               h->cfg.forget_bias, st);
     else
@@ -1450,6 +1462,18 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
           hipHostMalloc(&h->perr, 64, hipHostMallocMapped) != hipSuccess)
         return bail(NASR_ERR_HIP, "allocation of the persistent-recurrence buffers failed");
       *h->perr = 0;
+      const char* er = getenv("NASR_REC");
+      h->rec_f16 = !(er && std::string(er) == "f32");
+      if (h->rec_f16) {
+        bool g2 = false;
+        size_t wsf = 0;
+        for (size_t k = 0; k < nk; ++k) wsf += tph_scale_ws_floats(h->Hp, h->N4);
+        if (hipMalloc(&h->Ucs, nk * h->N4 * 4) != hipSuccess || hipMalloc(&h->Ucinv, nk * h->N4 * 4) != hipSuccess ||
+            !h->scws.ensure(wsf * 4, &g2))
+          return bail(NASR_ERR_HIP, "allocation of the recurrent-weight scales failed");
+        (void)hipMemsetAsync(h->Ucs, 0, nk * h->N4 * 4, h->st);
+        (void)hipMemsetAsync(h->Ucinv, 0, nk * h->N4 * 4, h->st);
+      }
       (void)hipMemsetAsync(h->Upf, 0, nk * h->imf * 4, h->st);
       (void)hipMemsetAsync(h->Upb, 0, nk * h->imb * 4, h->st);
       (void)hipMemsetAsync(h->xch, 0, persist_xch_floats(h->Hp) * 4, h->st);
@@ -1500,8 +1524,8 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       std::vector<int32_t> two((size_t)Bp, T);
       (void)hipMemcpyAsync(sq.p, two.data(), Bp * 4, hipMemcpyHostToDevice, h->st);
       const LstmDims dm{T, Bp, Bp, h->H, h->Hp, h->D};
-      launch_lstm_persist_fwd(dm, h->Upf, g.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(), h->xch, h->pctl,
-                              h->perr, nullptr, 1.f, h->st);
+      launch_lstm_persist_fwd(dm, h->Upf, h->rec_f16 ? h->Ucinv : nullptr, g.as<float>(), c.as<float>(), o.as<float>(),
+                              sq.as<int>(), h->xch, h->pctl, h->perr, nullptr, 1.f, h->st);
       launch_lstm_persist_bwd(dm, h->Upb, g.as<float>(), dg.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(),
                               h->xch, h->pctl, h->perr, nullptr, h->st);
       ok = hipStreamSynchronize(h->st) == hipSuccess && hipGetLastError() == hipSuccess && *h->perr == 0;
@@ -1531,7 +1555,7 @@ int nasr_destroy(nasr_handle h) {
   for (hipEvent_t e : h->ev_dx) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_bucket) (void)hipEventDestroy(e);
   drop_graphs(h);
-  for (float* p : {h->P, h->M, h->V, h->Gbase, h->Uf, h->Ub, h->WxT, h->Upf, h->Upb, h->xch})
+  for (float* p : {h->P, h->M, h->V, h->Gbase, h->Uf, h->Ub, h->WxT, h->Upf, h->Upb, h->xch, h->Ucs, h->Ucinv})
     if (p) (void)hipFree(p);
   if (h->WfTP) (void)hipFree(h->WfTP);
   if (h->WbTP) (void)hipFree(h->WbTP);

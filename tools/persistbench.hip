@@ -30,6 +30,7 @@ static double maxdiff(const float* a, const float* b, size_t n, double* maxabs) 
 int main(int argc, char** argv) {
   const int H = argc > 1 ? atoi(argv[1]) : 500, B = argc > 2 ? atoi(argv[2]) : 16, T = argc > 3 ? atoi(argv[3]) : 500;
   const int D = argc > 4 ? atoi(argv[4]) : 2, ragged = argc > 5 ? atoi(argv[5]) : 1;
+  const int f16 = argc > 6 ? atoi(argv[6]) : 1;      // forward recurrence on fp16 planes (the engine's default) or fp32
   const int Hp = (H + 63) / 64 * 64, Bp = (B + 15) / 16 * 16, N4 = 4 * Hp;
   const size_t R = (size_t)T * Bp;
   const LstmDims dm{T, B, Bp, H, Hp, D};
@@ -77,9 +78,24 @@ int main(int argc, char** argv) {
   for (int d = 0; d < D; ++d) {
     launch_repack_u(U + (size_t)d * Hp * N4, Uf + (size_t)d * Hp * N4, Ub + (size_t)d * Hp * N4, Hp, st);
   }
+  float *cs = nullptr, *cinv = nullptr;
+  if (f16) {   // column scales on the host: largest magnitude of every column of U into [2^14, 2^15)
+    std::vector<float> hs((size_t)D * N4), hi((size_t)D * N4);
+    for (int d = 0; d < D; ++d)
+      for (int c = 0; c < N4; ++c) {
+        float m = 0.f;
+        for (int k = 0; k < Hp; ++k) m = fmaxf(m, fabsf(hU[((size_t)d * Hp + k) * N4 + c]));
+        int e = 15;
+        if (m > 0.f) frexpf(m, &e);
+        hs[(size_t)d * N4 + c] = ldexpf(1.f, 15 - e);
+        hi[(size_t)d * N4 + c] = ldexpf(1.f, e - 15);
+      }
+    CK(hipMalloc(&cs, hs.size() * 4)); CK(hipMalloc(&cinv, hi.size() * 4));
+    CK(hipMemcpy(cs, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(cinv, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+  }
   {
     int64_t offs[2] = {0, (int64_t)Hp * N4};
-    launch_repack_persist(U, offs, D, Upf, Upb, Hp, st);
+    launch_repack_persist(U, offs, D, Upf, Upb, Hp, cs, st);
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms;
@@ -97,7 +113,7 @@ int main(int argc, char** argv) {
     // ---- forward, persistent
     CK(hipMemcpyAsync(gatesB, gates0, R * D * N4 * 4, hipMemcpyDeviceToDevice, st));
     CK(hipEventRecord(e0, st));
-    launch_lstm_persist_fwd(dm, Upf, gatesB, cB, outB, seq, xch, ctl, nullptr, nullptr, 1.0f, st);
+    launch_lstm_persist_fwd(dm, Upf, cinv, gatesB, cB, outB, seq, xch, ctl, nullptr, nullptr, 1.0f, st);
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGetLastError());
     CK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
