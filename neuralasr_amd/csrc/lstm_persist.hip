@@ -154,16 +154,18 @@ __global__ __launch_bounds__(256) void repack_persist_kernel(const float* __rest
   const int NU = Hp / 32, KW = 8 * NU, N4 = 4 * Hp;
   const int NOG = (KW + 63) / 64, KB = NOG * 4 * NU;
   const int64_t nf = (int64_t)32 * 4 * KW * 64, nb = (int64_t)32 * 4 * KB * 64;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nf + nb; e += (int64_t)gridDim.x * blockDim.x) {
-    if (e < nf) {
-      const int lane = e & 63;
-      int64_t x = e >> 6;
-      const int idx = (int)(x % KW); x /= KW;
+  const int64_t nfe = cs0 ? nf / 4 : nf;      // fp16 image: one work item per (chunk of 4 units, lane)
+  for (int64_t e0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e0 < nfe + nb; e0 += (int64_t)gridDim.x * blockDim.x) {
+    if (e0 < nfe) {
+      const int lane = e0 & 63;
+      int64_t x = e0 >> 6;
+      const int KWe = cs0 ? KW / 4 : KW;
+      const int idx = (int)(x % KWe) * (cs0 ? 4 : 1); x /= KWe;
       const int w = (int)(x & 3), m = (int)(x >> 2);
       const int bp = lane >> 2, g = lane & 3;
       if (!cs0) {
-        Upf[e] = bp < NU ? U[(size_t)(w * KW + idx) * N4 + 4 * (NU * m + bp) + g] : 0.f;
-      } else if ((idx & 3) == 0) {       // one thread per (chunk of 4 units, lane): both planes
+        Upf[e0] = bp < NU ? U[(size_t)(w * KW + idx) * N4 + 4 * (NU * m + bp) + g] : 0.f;
+      } else {                           // both planes of units idx .. idx+3
         const int col = 4 * (NU * m + bp) + g;
         const float sc = bp < NU ? cs0[(size_t)blockIdx.y * N4 + col] : 1.f;
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void repack_persist_kernel(const float* __rest
         dst[64] = p2;
       }
     } else {
-      const int64_t eb = e - nf;
+      const int64_t eb = e0 - nfe;
       const int lane = eb & 63;
       int64_t x = eb >> 6;
       const int idx = (int)(x % KB); x /= KB;
