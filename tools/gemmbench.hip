@@ -150,6 +150,19 @@ int main() {
       }
       printf("tph    %s split %d : %.3f ms  %.1f TF-equiv (+ %.3f ms for scales + planes of both operands)  rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, g.split_k, best,
              2.0 * c.M * c.N * c.K / best / 1e9, tsplit, sqrt(num / den), mx);
+      if (getenv("NASR_SWEEP")) {
+        for (int sp : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
+          if ((size_t)sp * c.M * c.N > (size_t)8 * 1024 * 4096 || (c.K + 15) / 16 / sp < 16) continue;
+          g.split_k = sp;
+          float b2 = 1e9f;
+          launch_gemm_tph(g, st);
+          for (int i = 0; i < 8; ++i) {
+            CK(hipEventRecord(a, st)); launch_gemm_tph(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); b2 = ms < b2 ? ms : b2;
+          }
+          printf("   sweep %s split %2d : %.3f ms\n", c.name, sp, b2);
+        }
+      }
     }
   }
   {  // fp16-plane helpers against the host: scales (rows and columns of a ragged, wide-range matrix) and column sums
