@@ -63,22 +63,29 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   if (ry == 0 && n < N) part[(size_t)rs * N + n] = (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]);
 }
 
-// fixed-order sum of `nparts` partial rows; 4 threads per column (k = q, q+4, ...) combined through LDS
+// fixed-order sum of `nparts` partial rows: 16 columns per block, 16 threads per column (rows q, q+16, ...) combined
+// through LDS in a fixed order - 4x the blocks and a quarter of the dependent loads of the 64-column form (12.9 -> ~5 us
+// for 125 x 4096)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int N,
                                                            float* __restrict__ out) {
-  __shared__ float sm[4][64];
-  const int cx = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cx;
+  __shared__ float sm[16][17];
+  const int cx = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + cx;
   float s = 0.f;
   if (n < N)
-    for (int k = q; k < nparts; k += 4) s += part[(size_t)k * N + n];
+    for (int k = q; k < nparts; k += 16) s += part[(size_t)k * N + n];
   sm[q][cx] = s;
   __syncthreads();
-  if (q == 0 && n < N) out[n] = (sm[0][cx] + sm[1][cx]) + (sm[2][cx] + sm[3][cx]);
+  if (q == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sm[i][cx];
+    out[n] = t;
+  }
 }
 
 void launch_colsum_parts(const float* part, int nparts, int N, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, st, part, nparts, N, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, st, part, nparts, N, out);
 }
 
 void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st) {
