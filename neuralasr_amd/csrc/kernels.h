@@ -162,10 +162,10 @@ void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Up
 // cinv (or NULL): [D][4*Hp] inverse column scales of this layer's matrices = the fp16 form of the forward image
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* cinv, float* gates, float* cbuf,
                              float* out, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
-                             float forget_bias, hipStream_t st);
+                             float forget_bias, hipStream_t st, bool ctl_zeroed = false);   // ctl_zeroed: the caller cleared *ctl
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
-                             float* fault, hipStream_t st);
+                             float* fault, hipStream_t st, bool ctl_zeroed = false);
 
 // ---- DeepSpeech dense stages (dense.hip): clipped ReLU + hash-defined dropout, in place ----
 void launch_dense_act(float* z, int R, int Bp, int B, int W, int ld, float clip, float p, uint32_t seed, uint32_t counter,

@@ -713,10 +713,10 @@ hipError_t persist_prepare() {
 
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* cinv, float* gates, float* cbuf,
                              float* out, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
-                             float forget_bias, hipStream_t st) {
+                             float forget_bias, hipStream_t st, bool ctl_zeroed) {
   PersistGeom gm = make_geom(dm);
   gm.fault = fault;
-  (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
+  if (!ctl_zeroed) (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(320);
 #define NASR_PF(NUV)                                                                                                  \
   if (cinv)                                                                                                           \
@@ -740,10 +740,10 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* 
 
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
-                             float* fault, hipStream_t st) {
+                             float* fault, hipStream_t st, bool ctl_zeroed) {
   PersistGeom gm = make_geom(dm);
   gm.fault = fault;
-  (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
+  if (!ctl_zeroed) (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(320);
 #define NASR_PB(NUV)                                                                                                   \
   hipLaunchKernelGGL((lstm_persist_bwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upb, gates, dgbuf, cbuf, dout, \

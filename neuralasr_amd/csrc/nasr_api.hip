@@ -747,11 +747,11 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
     if (!bwd)
       launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->rec_f16 ? h->Ucinv + k * h->N4 : nullptr,
                               h->gates[l].as<float>(), h->cbuf[l].as<float>(),
-                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->Gbase,
-                              h->cfg.forget_bias, st);
+                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl + 1 + l, h->perr, h->Gbase,
+                              h->cfg.forget_bias, st, true);
     else
       launch_lstm_persist_bwd(dm, h->Upb + k * h->imb, h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(),
-                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl, h->perr, h->Gbase, st);
+                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl + 1 + h->L + l, h->perr, h->Gbase, st, true);
     h->persist_used = true;
     HIPCHK(h, hipGetLastError());
     return NASR_OK;
@@ -954,6 +954,8 @@ int forward(nasr_ctx* h) {
   const int R = T * Bp;
   h->n_fwd_launch = 0;
   const int NC = h->pipe_chunks;
+  // the control blocks of this pass's persistent launches, cleared in one go (one per layer: run_steps)
+  if (h->persist) HIPCHK(h, hipMemsetAsync(h->pctl + 1, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
   for (int i = 0; i < h->npre; ++i) {
     PhaseScope ps(h, PH_XPROJ);
     int rc = dense_forward(h, i, i == 0 ? h->X0.as<float>() : h->Ybuf[i - 1].as<float>());
@@ -1163,6 +1165,7 @@ int backward(nasr_ctx* h) {
   const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp;
   const int R = T * Bp, Rp = h->Tp * Bp;
   const bool sr = h->cfg.merge == NASR_MERGE_STACK_RESHAPE && D == 2;
+  if (h->persist) HIPCHK(h, hipMemsetAsync(h->pctl + 1 + h->L, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
   {
     PhaseScope ps(h, PH_PROJCTC);
     const CtcDims d = ctc_dims(h);
@@ -1458,7 +1461,7 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       if (persist_prepare() != hipSuccess || hipMalloc(&h->Upf, nk * h->imf * 4) != hipSuccess ||
           hipMalloc(&h->Upb, nk * h->imb * 4) != hipSuccess ||
           hipMalloc(&h->xch, persist_xch_floats(h->Hp) * 4) != hipSuccess ||
-          hipMalloc(&h->pctl, sizeof(PersistCtl)) != hipSuccess ||
+          hipMalloc(&h->pctl, (size_t)(1 + 2 * h->L) * sizeof(PersistCtl)) != hipSuccess ||   // [0] census, then one per layer pass
           hipHostMalloc(&h->perr, 64, hipHostMallocMapped) != hipSuccess)
         return bail(NASR_ERR_HIP, "allocation of the persistent-recurrence buffers failed");
       *h->perr = 0;
