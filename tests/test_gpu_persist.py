@@ -175,3 +175,34 @@ def test_aborted_persistent_launch_voids_the_step_and_falls_back(monkeypatch):
     assert loss == pytest.approx(loss_o, rel=2e-5)
     assert e.get_adam_state()[2] == 1 and np.abs(e.get_params() - start).max() > 1e-4
     e.close()
+
+
+def test_fp16_plane_and_fp32_forward_recurrence_agree(monkeypatch):
+    """The persistent forward recurrence keeps U as two fp16 planes and multiplies on v_mfma_f32_4x4x4_16B_f16 (three
+    products per fp32 product, lstm_persist.hip); NASR_REC=f32 keeps fp32 planes and fp32 MFMAs.  Same logits, loss and
+    gradients to fp32 rounding - on weights whose columns differ by 8 decades (one scale per gate column)."""
+    spec = O.ModelSpec(15, 200, 2, True, 'concat', 8)
+    B, T = 9, 40
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=13, var_len=True, Lmin=1, Lmax=7)
+    params = rand_params(spec, 4)
+    rs = np.random.RandomState(0)
+    for i in (0, 2, 4, 6):                                  # kernels [I+H, 4H]: scale the recurrent rows' columns
+        I = params[i].shape[0] - spec.hidden
+        params[i][I:] *= 10.0 ** rs.uniform(-4, 0, size=(1, params[i].shape[1]))
+    out = {}
+    for mode in ('f16', 'f32'):
+        monkeypatch.setenv('NASR_REC', mode)
+        e = make_engine(spec)
+        assert e.recurrence_mode == 'persistent'
+        e.set_params(O.flatten(params))
+        logits = e.forward(feats, seq_len)
+        loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+        out[mode] = (logits, loss, grads)
+        e.close()
+    np.testing.assert_allclose(out['f16'][0], out['f32'][0], atol=2e-5)
+    assert out['f16'][1] == pytest.approx(out['f32'][1], rel=2e-6)
+    assert np.linalg.norm(out['f16'][2] - out['f32'][2]) <= 2e-5 * np.linalg.norm(out['f32'][2])
+    loss_o, _, grads_o, logits_o = O.network_loss_and_grads(
+        spec, [np.asarray(p, np.float32).astype(np.float64) for p in params], feats, seq_len, labels, label_len)
+    np.testing.assert_allclose(out['f16'][0], logits_o, atol=1e-4)
+    assert out['f16'][1] == pytest.approx(loss_o, rel=2e-5)
