@@ -26,16 +26,96 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+class Workload:
+    """Shape bookkeeping of one network (the fields nasr_model_cfg takes) - bench.py builds its inputs itself; only
+    the cpu_baseline leg touches oracle/."""
+
+    def __init__(self, feature_size, hidden, num_layers, bidirectional, merge, num_classes, pre=(), post=0,
+                 relu_clip=20.0, dropout=()):
+        self.feature_size, self.hidden, self.num_layers = feature_size, hidden, num_layers
+        self.bidirectional, self.merge, self.num_classes = bidirectional, merge, num_classes
+        self.pre, self.post, self.relu_clip, self.dropout = tuple(pre), post, relu_clip, tuple(dropout)
+
+    @property
+    def dirs(self):
+        return 2 if self.bidirectional else 1
+
+    @property
+    def deepspeech(self):
+        return bool(self.pre) or self.post > 0
+
+    @property
+    def proj_in(self):
+        return 2 * self.hidden if (self.bidirectional and self.merge == 'concat') else self.hidden
+
+    def layer_input(self, l):
+        if l == 0:
+            return self.pre[-1] if self.pre else self.feature_size
+        return self.hidden * self.dirs
+
+    def param_count(self):
+        n, w_in = 0, self.feature_size
+        for w in self.pre:
+            n += w + w_in * w
+            w_in = w
+        for l in range(self.num_layers):
+            n += self.dirs * ((self.layer_input(l) + self.hidden) * 4 * self.hidden + 4 * self.hidden)
+        last = self.proj_in
+        if self.post:
+            n += self.post + last * self.post
+            last = self.post
+        return n + last * self.num_classes + self.num_classes
+
+    def oracle_spec(self):
+        from oracle.nasr_oracle import ModelSpec      # cpu_baseline leg only
+        return ModelSpec(self.feature_size, self.hidden, self.num_layers, self.bidirectional, self.merge,
+                         self.num_classes, pre=self.pre, post=self.post, relu_clip=self.relu_clip, dropout=self.dropout)
+
+
 def workload_spec(name):
-    from oracle.nasr_oracle import ModelSpec      # shape bookkeeping + synthetic batch only
     if name == 'literal':
-        return ModelSpec(546, 500, 1, True, 'stack_reshape', 29), 'bilstm_ctc_net literal 1x500 bi stack_reshape'
+        return Workload(546, 500, 1, True, 'stack_reshape', 29), 'bilstm_ctc_net literal 1x500 bi stack_reshape'
     if name == 'lstm3':
-        return ModelSpec(546, 500, 3, False, 'none', 29), 'lstm_ctc_net 3x500 uni'
+        return Workload(546, 500, 3, False, 'none', 29), 'lstm_ctc_net 3x500 uni'
     if name == 'deepspeech':     # BASELINE.json configs[3]: networks/deepspeech.py at its own sizes, batch 32 per GPU
-        return (ModelSpec(546, 2048, 1, True, 'concat', 29, pre=(2048, 2048, 4096), post=2048, relu_clip=20.0,
-                          dropout=(0.05, 0.05, 0.05, 0.05)), 'deepspeech (3 dense + BiLSTM 2048 + dense), dropout 0.05')
-    return ModelSpec(546, 500, 3, True, 'concat', 29), 'bilstm_ctc_net 3x500 bi concat'
+        return (Workload(546, 2048, 1, True, 'concat', 29, pre=(2048, 2048, 4096), post=2048, relu_clip=20.0,
+                         dropout=(0.05, 0.05, 0.05, 0.05)), 'deepspeech (3 dense + BiLSTM 2048 + dense), dropout 0.05')
+    return Workload(546, 500, 3, True, 'concat', 29), 'bilstm_ctc_net 3x500 bi concat'
+
+
+def synth_batch(spec, B, T, seed=1234, var_len=False):
+    """BASELINE.md §4 synthetic batch: features N(0,1) zeroed past seq_len, labels U{1..C-2}, L ~ U{40..80} (scaled
+    with T), seq_len = T or U{T/2..T} sorted ascending (the size-sorted scp of preprocess_mfcc.py:33)."""
+    rs = np.random.RandomState(seed)
+    if var_len:
+        seq_len = np.sort(rs.randint(max(T // 2, 1), T + 1, size=B)).astype(np.int32)
+        seq_len[-1] = T
+    else:
+        seq_len = np.full(B, T, np.int32)
+    feats = rs.randn(B, T, spec.feature_size).astype(np.float32)
+    for b in range(B):
+        feats[b, seq_len[b]:] = 0
+    lmax = max(1, min(80, T * 80 // 500))
+    label_len = rs.randint(max(1, lmax // 2), lmax + 1, size=B).astype(np.int32)
+    label_len = np.minimum(label_len, np.maximum(seq_len // 2, 1)).astype(np.int32)
+    labels = np.zeros((B, int(label_len.max())), np.int32)
+    for b in range(B):
+        labels[b, :label_len[b]] = rs.randint(1, max(spec.num_classes - 1, 2), size=label_len[b])
+    return feats, seq_len, labels, label_len
+
+
+def init_params(tensors, seed=1):
+    """Random-init weights of the architecture in TF variable order (Engine.tensors()): glorot-uniform for every matrix,
+    zero biases - the defaults the reference's graph relies on."""
+    rs = np.random.RandomState(seed)
+    chunks = []
+    for _, _, rows, cols in tensors:
+        if cols == 1:
+            chunks.append(np.zeros(rows, np.float32))
+        else:
+            lim = np.sqrt(6.0 / (rows + cols))
+            chunks.append(rs.uniform(-lim, lim, size=rows * cols).astype(np.float32))
+    return np.concatenate(chunks)
 
 
 def algorithmic_bytes(spec, B, T):
@@ -106,6 +186,7 @@ def cpu_baseline(spec, B, seed):
     excluded) on a bounded sample of the same workload — same net and batch size, T sized by a short probe so the
     timed call takes ~10-20 s.  Falls back to the fp64 NumPy oracle if the C library cannot be built."""
     from oracle import nasr_oracle as O
+    spec = spec.oracle_spec()
     try:
         from oracle import cref
         cref.set_threads(cref.usable_cpus())           # honour the container's CPU quota
@@ -153,6 +234,17 @@ def cpu_baseline(spec, B, seed):
                              f'({int(seq_len.sum())} frames, {dt:.1f} s); Adam excluded'}
 
 
+PROFILE_FILES = {'pmc': 'pmc_traffic.json', 'stamps': 'persist_stamps.json'}
+
+
+def load_profile(name):
+    path = os.path.join(ROOT, 'profiles', PROFILE_FILES[name])
+    try:
+        return json.load(open(path)), os.path.join('profiles', PROFILE_FILES[name])
+    except Exception:      # noqa: BLE001 - a missing profile only blanks the fields that come from it
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -165,15 +257,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--per-step', action='store_true', help='per-timestep launches (lstm.hip) instead of the persistent recurrence')
-    ap.add_argument('--allreduce', default='auto', choices=['auto', 'bucketed', 'single'],
-                    help='N > 1: gradient exchange as one all-reduce after the backward pass, or per-layer buckets on a '
-                         'side stream under the rest of the backward pass; auto times both during warm-up')
+    ap.add_argument('--allreduce', default='auto', choices=['auto', 'bucketed', 'bucketed-eager', 'single'],
+                    help='N > 1: gradient exchange as one all-reduce after the backward pass (single), or per-layer buckets '
+                         'on a side stream under the rest of the backward pass, each released after the next persistent '
+                         'BPTT launch (bucketed) or as soon as it is complete (bucketed-eager); auto times all during warm-up')
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from neuralasr_amd.engine import Engine
-    from oracle import nasr_oracle as O
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -196,6 +288,7 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)
+    on_device = not use_dist or dist.get_backend() == 'nccl'
 
     spec, wname = workload_spec(args.workload)
     B, T = args.batch or (32 if args.workload == 'deepspeech' else 16), args.frames
@@ -212,8 +305,8 @@ def main():
     eng.set_graph_mode(not args.no_graph)
     if args.per_step:
         eng.set_recurrence_mode(False)
-    eng.set_params(O.flatten(O.init_params(spec, seed=1)).astype(np.float32))   # same weights on every rank
-    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1234 + rank, var_len=args.var_len)
+    eng.set_params(init_params(eng.tensors(), seed=1))   # same weights on every rank
+    feats, seq_len, labels, label_len = synth_batch(spec, B, T, seed=1234 + rank, var_len=args.var_len)
     eng.upload_batch(feats, seq_len, labels, label_len)
     frames = eng.resident_frames()
     gt = eng.grad_tensor() if use_dist else None
@@ -226,12 +319,16 @@ def main():
         except Exception as exc:              # noqa: BLE001 - fall back to the one-collective exchange
             print(f'bucketed all-reduce unavailable ({type(exc).__name__}: {exc}); using one all-reduce', file=sys.stderr)
             reducer = None
-    ar_mode = 'bucketed' if (reducer is not None and len(reducer.views) > 1) else 'single'
+    can_bucket = reducer is not None and len(reducer.views) > 1
+    ar_mode = (args.allreduce if args.allreduce != 'auto' else 'bucketed') if can_bucket else 'single'
+
+    def set_mode(mode):
+        eng.set_bucket_defer(mode != 'bucketed-eager')
 
     def step():
         eng.compute_grads()
         if use_dist:
-            if ar_mode == 'bucketed':
+            if ar_mode != 'single':
                 reducer.all_reduce()
             else:
                 dist.all_reduce(gt, op=dist.ReduceOp.SUM)
@@ -242,23 +339,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_scalar(x, op):
+        if not use_dist:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device='cuda' if on_device else 'cpu')
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
     ar_probe = None
-    if use_dist and world > 1 and args.allreduce == 'auto' and ar_mode == 'bucketed':
+    if use_dist and world > 1 and args.allreduce == 'auto' and can_bucket:
         # measure, don't guess: a few untimed steps each way (part of the warm-up), slowest rank decides for everybody
         probe = {}
-        for mode in ('single', 'bucketed'):
+        for mode in ('single', 'bucketed', 'bucketed-eager'):
             ar_mode = mode
+            set_mode(mode)
             step(); step()
             fence()
             t0 = time.perf_counter()
             for _ in range(4):
                 step()
             fence()
-            tt = torch.tensor([(time.perf_counter() - t0) / 4], device='cuda', dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            probe[mode] = float(tt.item()) * 1e3
-        ar_mode = 'bucketed' if probe['bucketed'] <= probe['single'] else 'single'
+            probe[mode] = reduce_scalar((time.perf_counter() - t0) / 4, dist.ReduceOp.MAX) * 1e3
+        ar_mode = min(probe, key=probe.get)
         ar_probe = probe
+    set_mode(ar_mode)
     for _ in range(args.warmup):
         step()
     fence()
@@ -266,17 +370,19 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    dt = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
+    dt = reduce_scalar(dt_own, dist.ReduceOp.MAX) if use_dist else dt_own
+    total_frames = reduce_scalar(frames, dist.ReduceOp.SUM) if use_dist else float(frames)
+    loss = eng.get_loss()                 # also surfaces a void step / an aborted persistent launch on this rank
+    # what every rank ran: a rank that fell back to the per-step kernels (or saw void steps) slows the whole job and
+    # would be invisible in rank 0's line otherwise
+    aborts, rearms = eng.persist_stats()
+    mine = {'rank': rank, 'ms_per_step': dt_own / args.steps * 1e3, 'recurrence': eng.recurrence_mode,
+            'persist_aborts': aborts, 'persist_rearms': rearms, 'frames': int(frames), 'loss': loss}
+    ranks = [mine]
     if use_dist:
-        tt = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ft = torch.tensor([frames], device='cuda', dtype=torch.float64)
-        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
-        total_frames = float(ft.item())
-    else:
-        total_frames = float(frames)
-    loss = eng.get_loss()
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
 
     # ---- the same step fed from host buffers (features cross PCIe every step): never `value`, reported beside it
     NH = 5
@@ -287,9 +393,27 @@ def main():
         step()
     fence()
     dt_h2d = (time.perf_counter() - t1) / NH
+    # ---- ... and with the NEXT batch staged through pinned memory on the copy stream while the step runs
+    # (nasr_stage_batch / nasr_commit_batch: what train_model's loader thread does)
+    def staged_loop(stage):
+        t = stage()
+        eng.commit_batch(t)
+        t = stage()
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(NH):
+            eng.commit_batch(t)
+            step()
+            t = stage()
+        fence()
+        d = (time.perf_counter() - t1) / NH
+        eng.discard_batch(t)
+        return d
+    dt_h2d_staged = staged_loop(lambda: eng.stage_batch(feats, seq_len, labels, label_len))
     # ---- and fed the way HipNetwork.train feeds it: features with the include_context structure of preprocess_mfcc.py
     # (utils.py:8-21) go over PCIe as their centre [B,T,numcep] slice and are re-stacked on the device
-    dt_ctx = None
+    dt_ctx = dt_ctx_staged = None
     if spec.feature_size == 21 * 26:
         from neuralasr_amd.utils import include_context
         rs = np.random.RandomState(77 + rank)
@@ -305,7 +429,8 @@ def main():
                 step()
             fence()
             dt_ctx = (time.perf_counter() - t1) / NH
-            eng.upload_batch(feats, seq_len, labels, label_len)      # back to the bench batch for the phase timings
+            dt_ctx_staged = staged_loop(lambda: eng.stage_batch(fctx, seq_len, labels, label_len, 10, 26))
+    eng.upload_batch(feats, seq_len, labels, label_len)      # back to the bench batch for the phase timings
     # ---- the gradient all-reduce alone (time per step and bus bandwidth), N > 1 only
     ar_ms = None
     if use_dist and world > 1:
@@ -314,9 +439,7 @@ def main():
         for _ in range(10):
             dist.all_reduce(gt, op=dist.ReduceOp.SUM)
         fence()
-        ar = torch.tensor([(time.perf_counter() - t2) / 10], device='cuda', dtype=torch.float64)
-        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
-        ar_ms = float(ar.item()) * 1e3
+        ar_ms = reduce_scalar((time.perf_counter() - t2) / 10, dist.ReduceOp.MAX) * 1e3
         gt.zero_()            # the summed buffer is not a gradient any more; the next compute_grads overwrites it
 
     # ---- per-phase / per-launch timing with HIP events on the engine's stream (a few extra steps)
@@ -346,14 +469,17 @@ def main():
         achieved = k_bytes / (k_us * 1e-6) / 1e9
         kname = ('lstm_persist_bwd_kernel' if dom_bwd else 'lstm_persist_fwd_kernel') if persistent else \
                 ('lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel')
-        pmc = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc_path):
-            try:
-                pj = json.load(open(pmc_path))
-                pmc = pj.get(args.workload, {}).get(kname)
-            except Exception:
-                pmc = None
+        # PMC figures of the same command (separate --pmc passes, tools/pmc_summary.py); the files are named in the line
+        pj, pmc_file = load_profile('pmc')
+        wkey = args.workload + ('_varlen' if args.var_len else '')
+        pmc = (pj or {}).get(wkey, {}).get(kname)
+        mfma_busy = ((pj or {}).get('mfma', {}).get(wkey, {}).get(kname) or {}).get('mfma_util')
+        sj, stamp_file = load_profile('stamps')
+        # the chip-wide MFMA floor of one timestep: D*B*H*4H MACs on 1024 SIMDs; forward as 3 fp16 4x4x4 products
+        # (8 cycles per 2048-FLOP MFMA), BPTT as fp32 4x4x1 (8 cycles per 512-FLOP MFMA), at the 2.4 GHz peak clock
+        macs = spec.dirs * 16 * 512 * 2048 if spec.hidden <= 512 else None      # padded Hp = 512, 16 utterance rows
+        floor_fwd = macs * 3 / 1024 / (1024 * 2.4e3) * 8 if macs else None        # us
+        floor_bwd = macs / 256 / (1024 * 2.4e3) * 8 if macs else None
         out = {
             'metric': f'audio-frames/sec (fwd+bwd+CTC+Adam) at batch {B} per GPU',
             'value': total_frames * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
@@ -367,43 +493,68 @@ def main():
                        'recurrence': eng.recurrence_mode,
                        'recurrence_forward_mfma': ('fp32 products from 2 fp16 planes of U and 2 fp16 parts of h (4x4x4 f16 MFMA)'
                                                    if os.environ.get('NASR_REC', 'f16') != 'f32' else 'fp32 4x4x1 MFMA'),
-                       'gemm': {'tp': 'fp32 products from 2 fp16 planes x 3 MFMA products, fp32 accumulation, power-of-two '
-                                      'row scales (gemm_tph.hip)',
-                                'tp3': 'fp32 products from 3 bf16 planes x 6 MFMA products, fp32 accumulation (gemm_tp.hip)',
-                                'bf16': 'as tp3, operands split inside the GEMM (gemm_bf16.hip)',
-                                'f32': 'fp32 MFMA (gemm.hip)'}.get(os.environ.get('NASR_GEMM', 'tp'), 'tp'),
+                       'gemm': 'fp32 products from 2 fp16 planes x 3 MFMA products, fp32 accumulation, power-of-two '
+                               'row scales (gemm_tph.hip); projection on fp32 MFMA (gemm.hip)',
                        'allreduce': (ar_mode if world > 1 else None)},
             'loss': loss,
+            'ranks': ranks,
             'roofline': {'bound': 'hbm', 'kernel': kname,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': pmc, 'bytes_per_launch': k_bytes, 'us_per_launch': k_us,
-                         'timesteps_per_launch': spl, 'fwd_step_us': fwd_us / spl, 'bwd_step_us': bwd_us / spl},
+                         'timesteps_per_launch': spl, 'fwd_step_us': fwd_us / spl, 'bwd_step_us': bwd_us / spl,
+                         # what the HBM actually moved for this kernel (PMC bytes / live launch time / peak): the kernel
+                         # keeps the recurrent matrix in registers, so this is far below `frac` by design
+                         'hbm_measured_frac': (pmc / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if pmc else None,
+                         'mfma_busy': mfma_busy,
+                         # what does bound it: the dependent chain of one timestep (hand-off + MFMA + cell update)
+                         'latency': {'step_us': (bwd_us if dom_bwd else fwd_us) / spl,
+                                     'mfma_floor_us': floor_bwd if dom_bwd else floor_fwd,
+                                     'fwd_step_us': fwd_us / spl, 'fwd_mfma_floor_us': floor_fwd,
+                                     'bwd_step_us': bwd_us / spl, 'bwd_mfma_floor_us': floor_bwd,
+                                     'phase_cycles': (sj or {}).get(wkey if wkey in (sj or {}) else 'bilstm3x500'),
+                                     'note': 'bound = per-timestep dependent chain inside one XCD (flag/payload hand-off '
+                                             'through L2, MFMA phase, cell update), not HBM; phase_cycles = in-kernel '
+                                             's_memtime stamps of wave 0 (tools/persistbench, NASR_PSTAMP build)'},
+                         'sources': {'traffic_mfma_busy': pmc_file, 'phase_cycles': stamp_file,
+                                     'us_per_launch': 'live HIP events on the engine stream (nasr_get_phase_times)'}},
             'roofline_step': {'bound': 'hbm', 'bytes_alg': A + W + R, 'bytes_compulsory': A + W,
                               'achieved': (A + W + R) / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': (A + W + R) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                              'frac': (A + W + R) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'frac_compulsory': (A + W) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             'roofline_mfma': None,
             'phases_ms': {k: round(v, 4) for k, v in phases.items() if k.endswith('_ms')},
             'incl_h2d': {'ms_per_step': dt_h2d * 1e3, 'value': float(frames) * world / dt_h2d, 'unit': 'frames/s',
-                         'note': 'features uploaded from host memory every step (PCIe-inclusive); rank-0 clock'},
+                         'note': 'features uploaded from host memory every step (PCIe-inclusive); rank-0 clock',
+                         'staged': {'ms_per_step': dt_h2d_staged * 1e3, 'value': float(frames) * world / dt_h2d_staged,
+                                    'note': 'the next batch staged through pinned memory on the copy stream while the '
+                                            'step runs (nasr_stage_batch + nasr_commit_batch)'}},
         }
-        # (ii) of SURVEY.md §8d: the dense contractions (everything hoisted out of the time loop) against the fp32 matrix
-        # peak the reference's arithmetic type would be held to; the phases include the plane / scale passes of the GEMMs
+        # (ii) of SURVEY.md §8d: the dense contractions (everything hoisted out of the time loop).  They run as THREE fp16
+        # MFMA products per fp32 product, so the instruction stream is priced against the dense fp16 matrix peak with the
+        # product count in; the fp32-equivalent rate is given beside it.  The phases include the plane / scale passes.
         gf_dense, gf_rec = algorithmic_flops(spec, B, T)
         t_dense = (phases['xproj_ms'] + phases['wgrad_ms'] + phases['proj_bwd_ms']) * 1e-3
-        out['roofline_mfma'] = {'bound': 'mfma', 'flops_alg': gf_dense, 'achieved': gf_dense / t_dense / 1e12,
-                                'peak': 157.3, 'unit': 'TFLOP/s', 'frac': gf_dense / t_dense / 1e12 / 157.3,
+        gemm_busy = ((pj or {}).get('mfma', {}).get(wkey, {}).get('gemm_tph_kernel') or {}).get('mfma_util')
+        out['roofline_mfma'] = {'bound': 'mfma', 'flops_alg': gf_dense, 'mfma_products_per_fp32_product': 3,
+                                'achieved': 3 * gf_dense / t_dense / 1e12, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                'frac': 3 * gf_dense / t_dense / 1e12 / 2500.0,
+                                'fp32_equivalent_tflops': gf_dense / t_dense / 1e12,
+                                'mfma_busy_gemm_tph_kernel': gemm_busy,
                                 'note': 'hoisted GEMMs (input projections, input / weight / recurrent-weight gradients, dense '
-                                        'stages, projection backward) over the xproj + wgrad + proj_bwd phases; peak = fp32 '
-                                        'MFMA (v_mfma_f32_32x32x2_f32); the GEMMs run fp32-accurate products on the 16-bit '
-                                        'matrix cores, which is how frac can exceed 1',
+                                        'stages, projection backward) over the xproj + wgrad + proj_bwd phases; achieved = 3 x '
+                                        'algorithmic FLOP (the fp16 MFMA products issued per fp32 product) / phase time; peak = '
+                                        'dense fp16 MFMA (MI355X_MICROARCH.md); mfma_busy from the PMC pass',
                                 'recurrent_flops': gf_rec,
-                                'recurrent_step_us': {'fwd': fwd_us / spl, 'bwd': bwd_us / spl,
-                                                      'dependent_launch_floor_us': 1.55}}
+                                'sources': {'mfma_busy': pmc_file}}
         if dt_ctx is not None:
             out['incl_h2d']['context_upload'] = {
                 'ms_per_step': dt_ctx * 1e3, 'value': float(frames) * world / dt_ctx,
                 'note': 'context-stacked features uploaded as their centre slice, stacking rebuilt on the device '
-                        '(nasr_upload_batch_context, what HipNetwork.train does)'}
+                        '(nasr_upload_batch_context)',
+                'staged': {'ms_per_step': dt_ctx_staged * 1e3, 'value': float(frames) * world / dt_ctx_staged,
+                           'vs_resident': dt_ctx_staged * 1e3 / ms,
+                           'note': 'the same through nasr_stage_batch_context + nasr_commit_batch (what '
+                                   'HipNetwork.train does under train_model)'}}
         if ar_ms is not None:
             gbytes = gt.numel() * 4 / 1e9
             out['allreduce'] = {'ms': ar_ms, 'bytes': gt.numel() * 4,
@@ -412,7 +563,8 @@ def main():
                                 'probe_ms_per_step': ar_probe,
                                 'note': 'ms / bus_GBps: ONE all-reduce of the whole buffer, timed alone; mode = how the '
                                         'timed steps exchange gradients (bucketed: per-layer buckets on a side stream '
-                                        'under the rest of the backward pass)'}
+                                        'under the rest of the backward pass, each released after the next persistent '
+                                        'BPTT launch; bucketed-eager: released at once)'}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, B, 1234)
         else:

@@ -155,7 +155,27 @@ int nasr_upload_batch(nasr_handle h, const float* feats, const int32_t* seq_len,
 int nasr_upload_batch_context(nasr_handle h, const float* centre, const float* pad_value, int numcontext, int numcep,
                               const int32_t* seq_len, const int32_t* labels, const int32_t* label_len, int B, int T,
                               int Lmax);
+/* The input pipeline's half of the step (dataset.py:33-40 loads and train.py:23-26 times the NEXT batch inside the
+ * step): nasr_stage_batch copies a batch into one of the handle's staging slots - host side
+ * through pinned memory (hipHostMalloc), device side with hipMemcpyAsync on the handle's COPY stream - while the
+ * compute stream is busy with the current step, and returns a ticket; nasr_commit_batch(ticket) makes that batch the
+ * resident one (the compute stream waits for the slot's copy event; no host sync).  At most two batches
+ * staged ahead (NASR_ERR_STATE beyond that); a synchronous upload always finds a slot.  nasr_stage_batch* may be called from another host thread than the rest
+ * of the handle's calls (a loader thread); everything else stays one thread per handle.  The synchronous
+ * nasr_upload_batch* = stage on the compute stream + commit. */
+int nasr_stage_batch(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                     const int32_t* label_len, int B, int T, int Lmax, int* ticket);
+int nasr_stage_batch_context(nasr_handle h, const float* centre, const float* pad_value, int numcontext, int numcep,
+                             const int32_t* seq_len, const int32_t* labels, const int32_t* label_len, int B, int T,
+                             int Lmax, int* ticket);
+int nasr_commit_batch(nasr_handle h, int ticket);
+int nasr_discard_batch(nasr_handle h, int ticket);   /* give a staged batch's slot back unused */
 int nasr_compute_grads(nasr_handle h);          /* forward+CTC+backward on the resident batch (async) */
+/* In persistent mode bucket i's event is held back over the NEXT persistent BPTT launch (the layer below's), so that
+ * a collective released by nasr_grad_bucket_wait co-runs with that layer's GEMM phase rather than with a launch whose
+ * hand-offs want every CU's memory queue to themselves (default on, NASR_BUCKET_DEFER=0 at create); 0 records every
+ * bucket's event as soon as its gradients are complete. */
+int nasr_set_bucket_defer(nasr_handle h, int defer);
 void* nasr_grad_device_ptr(nasr_handle h);
 int64_t nasr_grad_device_count(nasr_handle h);
 int nasr_grad_bucket_count(nasr_handle h);
@@ -212,6 +232,11 @@ int nasr_set_graph_mode(nasr_handle h, int enabled); /* capture the per-timestep
  * (nasr_step_void) and this handle continues on the per-step kernels. */
 int nasr_get_recurrence_mode(nasr_handle h);
 int nasr_set_recurrence_mode(nasr_handle h, int persistent);
+/* After an abort the handle serves NASR_PERSIST_REARM (default 200; 0 = never) clean steps on the per-step kernels,
+ * then repeats the placement census of nasr_create at the start of a step and returns to the persistent kernels if it
+ * passes; every further abort doubles the wait.  aborts / rearms: how often each has happened on this handle (a rank
+ * that sits on the per-step kernels slows every rank of a data-parallel job: bench.py reports these per rank). */
+int nasr_get_persist_stats(nasr_handle h, int* aborts, int* rearms);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ SYMBOLS = [
     'nasr_upload_batch_context', 'nasr_label_error_rate', 'nasr_set_step_decode', 'nasr_get_decoded', 'nasr_ctc_beam_search', 'nasr_get_loss', 'nasr_resident_frames',
     'nasr_set_profiling', 'nasr_get_phase_times', 'nasr_set_graph_mode',
     'nasr_get_recurrence_mode', 'nasr_set_recurrence_mode', 'nasr_set_dropout_state', 'nasr_get_dropout_state',
-    'nasr_step_void',
+    'nasr_step_void', 'nasr_get_persist_stats', 'nasr_stage_batch', 'nasr_stage_batch_context', 'nasr_commit_batch',
+    'nasr_discard_batch', 'nasr_set_bucket_defer',
 ]
 
 
@@ -117,6 +118,12 @@ def load():
         'nasr_set_dropout_state': (c_int, [H, c_uint32, c_uint32]),
         'nasr_get_dropout_state': (c_int, [H, POINTER(c_uint32), POINTER(c_uint32)]),
         'nasr_step_void': (c_int, [H, POINTER(c_int)]),
+        'nasr_get_persist_stats': (c_int, [H, POINTER(c_int), POINTER(c_int)]),
+        'nasr_stage_batch': (c_int, [H, fp, ip, ip, ip, c_int, c_int, c_int, POINTER(c_int)]),
+        'nasr_stage_batch_context': (c_int, [H, fp, fp, c_int, c_int, ip, ip, ip, c_int, c_int, c_int, POINTER(c_int)]),
+        'nasr_commit_batch': (c_int, [H, c_int]),
+        'nasr_discard_batch': (c_int, [H, c_int]),
+        'nasr_set_bucket_defer': (c_int, [H, c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

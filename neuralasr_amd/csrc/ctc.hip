@@ -10,7 +10,7 @@
 // Kernel split: (1) logZ per (t,b) row, one wave per row; (2) alpha and beta recursions, one workgroup per
 // utterance, wave 0 = alpha, wave 1 = beta, the lattice column lives in registers (KS consecutive states per
 // lane), neighbours come over wave shuffles, so a timestep has no barrier and no LDS; emissions are
-// prefetched four frames ahead; (3) gradient, one wave per (t,b) row, class posteriors binned in LDS.
+// prefetched four frames ahead; (3) gradient, one wave per (t,b) row, class posteriors summed in a fixed order.
 #include "kernels.h"
 
 #include <cstdlib>
@@ -326,15 +326,20 @@ void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* l
 }
 
 // ------------------------------------------------------------------ (3) gradient, in place over the logits
+// One wave per (t,b) row.  The posterior of class k is the sum of exp(alpha+beta-logp) over the lattice states that carry
+// k, in a FIXED order (no atomics: two runs give the same bits): every lane turns its own states into weights in LDS;
+// the blank (all even states) is a per-lane sum in state order + the wave's xor tree; label k is summed by lane k over
+// the positions of k in the utterance's label in ascending order - cstart [B][C+1] / cpos [B][Lmax] is the label sorted
+// by class (a counting sort the host does once per upload, nasr_api.hip).
 __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logits, const float* __restrict__ logz,
-                                                       const int* __restrict__ labels,
                                                        const int* __restrict__ label_len,
                                                        const int* __restrict__ seq_len,
+                                                       const int* __restrict__ cstart, const int* __restrict__ cpos,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        const double* __restrict__ aoff, const double* __restrict__ boff,
                                                        const double* __restrict__ logp, float scale, int Tp, int B,
                                                        int Bp, int C, int Cp, int Lmax, int KS, int Tws) {
-  extern __shared__ __attribute__((aligned(16))) float bins_all[];
+  extern __shared__ __attribute__((aligned(16))) float wl_all[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + wv;
   if (row >= Tp * Bp) return;
@@ -344,38 +349,45 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logit
     for (int c = lane; c < Cp; c += 64) x[c] = 0.f;
     return;
   }
-  float* bins = bins_all + (size_t)wv * Cp;
-  for (int c = lane; c < Cp; c += 64) bins[c] = 0.f;
+  float* wl = wl_all + (size_t)wv * KS * 64;      // weight of state s at wl[s]
   const int L = label_len[b], S = 2 * L + 1;
   const float coff = (float)(aoff[(size_t)b * Tws + t] + boff[(size_t)b * Tws + t] - logp[b]);
-  const int* lab = labels + (size_t)b * Lmax;
   const float* al = alpha + ((size_t)b * Tws + t) * KS * 64;
   const float* be = beta + ((size_t)b * Tws + t) * KS * 64;
-  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float blank = 0.f;
   for (int i = 0; i < KS; ++i) {
     const int s = lane * KS + i;
-    if (s < S) {
-      const int k = (s & 1) ? lab[s >> 1] : C - 1;
-      const float wgt = __expf(al[i * 64 + lane] + be[i * 64 + lane] + coff);
-      atomicAdd(&bins[k], wgt);
-    }
+    const float wgt = s < S ? __expf(al[i * 64 + lane] + be[i * 64 + lane] + coff) : 0.f;
+    wl[s] = wgt;
+    if (!(s & 1)) blank += wgt;
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
+  blank = wave_sum(blank);                         // fixed xor tree
+  __builtin_amdgcn_s_waitcnt(0xc07f);              // this wave's LDS writes (no other wave reads them)
   const float z = logz[row];
+  const int* cs = cstart + (size_t)b * (C + 1);
+  const int* cp = cpos + (size_t)b * Lmax;
   for (int c = lane; c < Cp; c += 64) {
     float g = 0.f;
-    if (c < C) g = (__expf(x[c] - z) - bins[c]) * scale;
+    if (c < C) {
+      float post = blank;
+      if (c < C - 1) {
+        post = 0.f;
+        const int j1 = cs[c + 1];
+        for (int j = cs[c]; j < j1; ++j) post += wl[2 * cp[j] + 1];
+      }
+      g = (__expf(x[c] - z) - post) * scale;
+    }
     x[c] = g;
   }
 }
 
-void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* labels, const int* label_len,
-                     const int* seq_len, const float* alpha, const float* beta, const double* aoff,
+void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* label_len, const int* seq_len,
+                     const int* cstart, const int* cpos, const float* alpha, const float* beta, const double* aoff,
                      const double* boff, const double* logp, float scale, hipStream_t st) {
   const int rows = d.Tp * d.Bp;
-  const int rpb = d.Cp <= 2048 ? 4 : 1;
-  hipLaunchKernelGGL(ctc_grad_kernel, dim3((rows + rpb - 1) / rpb), dim3(64 * rpb), (size_t)rpb * d.Cp * 4, st, logits,
-                     logz, labels, label_len, seq_len, alpha, beta, aoff, boff, logp, scale, d.Tp, d.B, d.Bp, d.C, d.Cp,
+  const int rpb = 4;
+  hipLaunchKernelGGL(ctc_grad_kernel, dim3((rows + rpb - 1) / rpb), dim3(64 * rpb), (size_t)rpb * d.KS * 64 * 4, st, logits,
+                     logz, label_len, seq_len, cstart, cpos, alpha, beta, aoff, boff, logp, scale, d.Tp, d.B, d.Bp, d.C, d.Cp,
                      d.Lmax, d.KS, d.Tws);
 }
 

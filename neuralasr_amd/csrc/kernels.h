@@ -184,8 +184,9 @@ void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* l
                            const int* label_len, const int* seq_len, float* alpha, float* beta, double* aoff,
                            double* boff, float* nll, double* logp, hipStream_t st);
 // in place: logits -> d(mean nll)/dlogits
-void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* labels, const int* label_len,
-                     const int* seq_len, const float* alpha, const float* beta, const double* aoff,
+// cstart [B][C+1], cpos [B][Lmax]: the label positions of every utterance sorted by class (ascending inside a class)
+void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const int* label_len, const int* seq_len,
+                     const int* cstart, const int* cpos, const float* alpha, const float* beta, const double* aoff,
                      const double* boff, const double* logp, float scale, hipStream_t st);
 void launch_mean(const float* v, int n, float* out, hipStream_t st);
 void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, int* argmax_ws, int* ids, int* lens,

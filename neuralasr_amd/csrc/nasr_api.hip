@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,29 @@ struct GraphKey {
   }
 };
 
+// One uploaded batch: the caller's arrays in HBM (features as given, or their centre slice + pad values) and the small
+// integer arrays of the step packed into one "meta" buffer, with pinned host mirrors.  One slot is the
+// resident batch, others take the NEXT batches while the step runs (nasr_stage_batch: copies on the handle's copy
+// stream from pinned memory), so the upload of dataset.py:33-40's next batch leaves the timed step.
+constexpr int NSLOT = 4;           // the resident batch + up to NSTAGE staged ahead + one always free for a synchronous upload
+constexpr int NSTAGE = 2;
+enum SlotState { SLOT_FREE = 0, SLOT_FILLING, SLOT_STAGED, SLOT_RESIDENT };
+struct BatchSlot {
+  DevBuf dfeats, dmeta;
+  void *hfeats = nullptr, *hmeta = nullptr;      // hipHostMalloc
+  size_t hfeats_cap = 0, hmeta_cap = 0;
+  hipEvent_t ev_copy = nullptr, ev_released = nullptr;
+  bool copy_valid = false, released_valid = false;
+  int state = SLOT_FREE;
+  unsigned gen = 0;                              // ticket = slot index | gen << 8
+  // shape and layout of what is in it
+  int B = 0, T = 0, Lmax = 0, Bp = 0, Tp = 0, ctx = 0, ncep = 0;
+  bool has_labels = false, centre = false;
+  int64_t frames = 0;
+  size_t o_seq = 0, o_lablen = 0, o_labels = 0, o_cstart = 0, o_cpos = 0, o_rowmap = 0;   // int offsets into meta
+  int32_t* meta_d() const { return dmeta.as<int32_t>(); }
+};
+
 }  // namespace
 
 struct nasr_ctx {
@@ -96,7 +120,13 @@ struct nasr_ctx {
   bool persist = false;
   bool persist_ok = false;             // the device passed the census at create time
   bool persist_used = false;           // a persistent launch is in flight since the last check of *perr
-  int adam_unverified = 0;             // Adam launches since the last check of the step's fault word
+  int adam_unverified = 0;             // 1: an Adam launch followed the compute_grads whose fault word is still unread
+  // re-arming the persistent recurrence after an abort (persist_check): the per-step kernels serve `rearm_after` clean
+  // steps, then the census of nasr_create runs again and, if it passes, the persistent kernels come back; every further
+  // abort doubles the wait.  NASR_PERSIST_REARM sets the first wait (0 = never re-arm).
+  bool persist_wanted = false;         // the persistent mode is what this handle should run when the device allows it
+  int64_t rearm_after = 0, rearm_wait = 0, clean_steps = 0;
+  int persist_aborts = 0, persist_rearms = 0;
   float *Upf = nullptr, *Upb = nullptr;   // [L][D] operand images
   // forward recurrence on fp16 planes of U (v_mfma_f32_4x4x4_16B_f16, lstm_persist.hip): column scales / inverse scales of
   // every (layer, direction) matrix, [L*D][N4] each, measured after every optimiser step.  NASR_REC=f32 keeps fp32 MFMAs.
@@ -158,6 +188,10 @@ struct nasr_ctx {
   std::vector<std::pair<int64_t, int64_t>> buckets;
   std::vector<hipEvent_t> ev_bucket;
   std::vector<int> bucket_of_layer;          // LSTM layer -> bucket whose last gradients are that layer's (-1: none)
+  // Persistent mode: bucket(l)'s event is recorded AFTER the persistent BPTT launch of layer l-1 instead of right after
+  // weight_grads(l), so that a collective released by it co-runs with the GEMM phase of layer l-1, not with the launch
+  // that wants every CU's memory queue to itself (nasr_set_bucket_defer; NASR_BUCKET_DEFER=0 at create).
+  bool bucket_defer = true;
   float* WxT = nullptr;                // per layer [D*N4][Ip]: transposed input weights (K-contiguous B operand)
   std::vector<int64_t> off_wxt;
   int64_t adam_step = 0;
@@ -168,10 +202,18 @@ struct nasr_ctx {
   int B = 0, Bp = 0, T = 0, Lmax = 0, Tp = 0, KS = 1;
   int64_t frames = 0;
   std::vector<int32_t> h_seq;
+  BatchSlot slots[NSLOT];
+  BatchSlot* cur = nullptr;                  // the resident batch
+  hipStream_t cst = nullptr;                 // copy stream of nasr_stage_batch
+  std::mutex slot_mu;                        // slot states (nasr_stage_batch may run on a loader thread)
+  int slot_rr = 0;
+  // device arrays of the resident batch (inside cur->dmeta / cur->dfeats)
+  int32_t *seq_p = nullptr, *lablen_p = nullptr, *labels_p = nullptr, *cstart_p = nullptr, *cpos_p = nullptr,
+          *rowmap_p = nullptr;
 
   DevBuf XTP, X0TTP, OTTP0, OTTP1, GTP, GTTP;   // tiled-plane copies of activations / dG (gemm_tp)
-  DevBuf X0T, outT0, outT1, dGT, feats_bm, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, seq, labels, lablen,
-      rowmap, slabs, csws, amax, ids, lens, stage;
+  DevBuf X0T, outT0, outT1, dGT, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, slabs, csws, amax, ids, lens,
+      stage;
   std::vector<DevBuf> gates, outb, cbuf;
   std::vector<DevBuf> doutL, hstateL, partialL, dcstateL, dgL;   // one each, or one per layer when pipelined
 
@@ -260,6 +302,7 @@ inline ActScale dense_in_scale(const nasr_ctx* h, int i) {
 }
 
 int repack(nasr_ctx* h);
+void drop_graphs(nasr_ctx* h);
 
 int persist_check(nasr_ctx* h) {
   if (!h->persist_used) return NASR_OK;
@@ -269,10 +312,63 @@ int persist_check(nasr_ctx* h) {
   *reinterpret_cast<volatile unsigned*>(h->perr) = 0;
   h->persist = false;
   h->persist_ok = false;
+  h->persist_aborts += 1;
+  h->clean_steps = 0;
+  h->rearm_wait = h->persist_aborts <= 1 ? h->rearm_after : std::min<int64_t>(h->rearm_wait * 2, (int64_t)1 << 20);
   (void)repack(h);   // operand images of the per-step kernels
   return h->fail(NASR_ERR_HIP, "persistent recurrence aborted (code " + std::to_string(code) +
                                    ": 1 = hand-off timeout, 2 = workgroup placement); the results of this step are "
-                                   "invalid, later steps use the per-step kernels");
+                                   "invalid, later steps use the per-step kernels" +
+                                   (h->rearm_wait > 0 ? " (the persistent kernels are tried again after " +
+                                                            std::to_string(h->rearm_wait) + " clean steps)"
+                                                      : ""));
+}
+
+// Census: two steps of both persistent kernels on a zero layer.  A chip that does not place 32 workgroups on each of
+// its 8 XCDs (partition modes, masked CUs, a co-tenant) is detected here and served by the per-step kernels.
+// Synchronises the stream.
+bool persist_census(nasr_ctx* h) {
+  const int Bp = 16, T = 2;
+  const size_t R = (size_t)T * Bp;
+  DevBuf g, c, o, dg, sq;
+  bool grew = false;
+  bool ok = g.ensure(R * h->D * h->N4 * 4, &grew) && c.ensure(R * h->D * h->Hp * 4, &grew) &&
+            o.ensure(R * h->D * h->Hp * 4, &grew) && dg.ensure(R * h->D * h->N4 * 4, &grew) && sq.ensure(Bp * 4, &grew);
+  if (ok) {
+    (void)hipMemsetAsync(g.p, 0, R * h->D * h->N4 * 4, h->st);
+    (void)hipMemsetAsync(o.p, 0, R * h->D * h->Hp * 4, h->st);
+    std::vector<int32_t> two((size_t)Bp, T);
+    (void)hipMemcpyAsync(sq.p, two.data(), Bp * 4, hipMemcpyHostToDevice, h->st);
+    const LstmDims dm{T, Bp, Bp, h->H, h->Hp, h->D};
+    launch_lstm_persist_fwd(dm, h->Upf, h->rec_f16 ? h->Ucinv : nullptr, g.as<float>(), c.as<float>(), o.as<float>(),
+                            sq.as<int>(), h->xch, h->pctl, h->perr, nullptr, 1.f, h->st);
+    launch_lstm_persist_bwd(dm, h->Upb, g.as<float>(), dg.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(),
+                            h->xch, h->pctl, h->perr, nullptr, h->st);
+    ok = hipStreamSynchronize(h->st) == hipSuccess && hipGetLastError() == hipSuccess && *h->perr == 0;
+  }
+  for (DevBuf* b : {&g, &c, &o, &dg, &sq}) b->release();
+  *h->perr = 0;
+  return ok;
+}
+
+// After `rearm_wait` clean steps on the per-step kernels: run the census again and go back to the persistent kernels
+// (called at the start of a step, before anything of it is enqueued).
+void persist_rearm(nasr_ctx* h) {
+  if (h->persist || !h->persist_wanted || h->persist_aborts == 0 || h->rearm_wait <= 0 || !h->Upf) return;
+  if (++h->clean_steps <= h->rearm_wait) return;   // `rearm_wait` whole steps ran on the per-step kernels since the abort
+  h->clean_steps = 0;
+  if (hipStreamSynchronize(h->st) != hipSuccess) return;
+  // the operand images of the persistent kernels are stale (repack() only maintains the mode in use): rebuild first
+  h->persist = true;
+  if (repack(h) != NASR_OK || !persist_census(h)) {
+    h->persist = false;
+    h->rearm_wait = std::min<int64_t>(h->rearm_wait * 2, (int64_t)1 << 20);
+    (void)repack(h);
+    return;
+  }
+  h->persist_ok = true;
+  h->persist_rearms += 1;
+  drop_graphs(h);
 }
 
 int sync_checked(nasr_ctx* h) {
@@ -548,7 +644,6 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   if (KS > 16) return h->fail(NASR_ERR_ARG, "label length > 511 not supported by the CTC lattice kernel");
   bool grew = false;
   bool ok = true;
-  ok &= h->feats_bm.ensure((size_t)B * T * h->F * 4, &grew);
   ok &= h->X0.ensure(R * h->Fp * 4, &grew);
   for (size_t i = 0; i < h->doutL.size(); ++i) {
     ok &= h->doutL[i].ensure(R * D * Hp * 4, &grew);
@@ -600,10 +695,6 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->logp.ensure((size_t)Bp * 8, &grew);
   ok &= h->nll.ensure((size_t)Bp * 4, &grew);
   ok &= h->loss.ensure(16, &grew);
-  ok &= h->seq.ensure((size_t)Bp * 4, &grew);
-  ok &= h->labels.ensure((size_t)std::max(1, B * std::max(Lmax, 1)) * 4, &grew);
-  ok &= h->lablen.ensure((size_t)Bp * 4, &grew);
-  ok &= h->rowmap.ensure((size_t)Tp * Bp * 4, &grew);
   int csw = std::max(D * N4, h->Cp);
   for (int i = 0; i < h->ndense; ++i) csw = std::max(csw, h->dWp[i]);
   // column-sum partials: 32 rows of launch_colsum, or the 64-row partials of the fused split pass (tp_split2_parts)
@@ -653,9 +744,49 @@ int validate_batch(nasr_ctx* h, const int32_t* seq_len, const int32_t* labels, c
   return NASR_OK;
 }
 
-int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_t* labels, const int32_t* label_len,
-           int B, int T, int Lmax, const float* centre = nullptr, const float* pad_value = nullptr, int ctx = 0,
-           int ncep = 0) {
+bool pinned_ensure(void** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return true;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = bytes + bytes / 8;
+  if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) return false;
+  *cap = want;
+  return true;
+}
+
+// Takes a free slot (round robin), marks it FILLING.  NULL when every slot holds a staged or the resident batch.
+BatchSlot* slot_acquire(nasr_ctx* h, bool for_stage) {
+  std::lock_guard<std::mutex> lk(h->slot_mu);
+  if (for_stage) {   // staged batches never take the slot a synchronous upload (validate, decode, ...) needs
+    int ahead = 0;
+    for (const BatchSlot& s : h->slots) ahead += s.state == SLOT_STAGED || s.state == SLOT_FILLING;
+    if (ahead >= NSTAGE) return nullptr;
+  }
+  for (int k = 0; k < NSLOT; ++k) {
+    BatchSlot& s = h->slots[(h->slot_rr + k) % NSLOT];
+    if (s.state == SLOT_FREE) {
+      h->slot_rr = (h->slot_rr + k + 1) % NSLOT;
+      s.state = SLOT_FILLING;
+      s.gen += 1;
+      return &s;
+    }
+  }
+  return nullptr;
+}
+
+void slot_set_state(nasr_ctx* h, BatchSlot* s, int st) {
+  std::lock_guard<std::mutex> lk(h->slot_mu);
+  s->state = st;
+}
+
+// Copies one batch into slot s: the integer arrays through the slot's pinned meta buffer, the features from the caller's
+// memory (`pinned_feats` false: hipMemcpyAsync from pageable memory, which returns when the source may be reused) or
+// through the slot's pinned feature buffer (true: the H2D is a plain DMA that overlaps whatever the compute stream runs).
+// All device copies go to stream cs and end with the slot's ev_copy.
+int slot_fill(nasr_ctx* h, BatchSlot* s, const float* feats, const int32_t* seq_len, const int32_t* labels,
+              const int32_t* label_len, int B, int T, int Lmax, const float* centre, const float* pad_value, int ctx,
+              int ncep, hipStream_t cs, bool pinned_feats) {
   if ((!feats && !centre) || !seq_len) return h->fail(NASR_ERR_ARG, "null input buffer");
   if (centre && (!pad_value || ctx < 0 || ncep < 1 || (2 * ctx + 1) * ncep != h->F))
     return h->fail(NASR_ERR_ARG, "context upload: feature_size must equal (2*numcontext+1)*numcep");
@@ -663,9 +794,106 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
   int rc = validate_batch(h, seq_len, labels, label_len, B, T, Lmax);
   if (rc) return rc;
   HIPCHK(h, hipSetDevice(h->device));
-  rc = ensure_shape(h, B, T, labels ? Lmax : 0);
+  const int Bp = rup(B, 16), Tp = nasr_logit_frames(h, T), C = h->C, Lm = std::max(labels ? Lmax : 0, 1);
+  const bool sr = h->cfg.merge == NASR_MERGE_STACK_RESHAPE && h->D == 2;
+  // meta layout (int32): seq [Bp] | lablen [Bp] | labels [B*Lm] | cstart [B*(C+1)] | cpos [B*Lm] | rowmap [Tp*Bp]
+  s->o_seq = 0;
+  s->o_lablen = s->o_seq + Bp;
+  s->o_labels = s->o_lablen + Bp;
+  s->o_cstart = s->o_labels + (size_t)B * Lm;
+  s->o_cpos = s->o_cstart + (labels ? (size_t)B * (C + 1) : 0);
+  s->o_rowmap = s->o_cpos + (size_t)B * Lm;
+  const size_t nmeta = s->o_rowmap + (sr ? (size_t)Tp * Bp : 0);
+  const size_t nfeat = centre ? (size_t)B * T * ncep + B : (size_t)B * T * h->F;
+  bool grew = false;
+  if (!s->dmeta.ensure(nmeta * 4, &grew) || !s->dfeats.ensure(nfeat * 4, &grew) ||
+      !pinned_ensure(&s->hmeta, &s->hmeta_cap, nmeta * 4) ||
+      (pinned_feats && !pinned_ensure(&s->hfeats, &s->hfeats_cap, nfeat * 4)))
+    return h->fail(NASR_ERR_HIP, "allocation of a batch slot failed");
+  if (s->copy_valid) HIPCHK(h, hipEventSynchronize(s->ev_copy));          // the pinned mirrors are free to overwrite
+  if (s->released_valid && cs != h->st) HIPCHK(h, hipStreamWaitEvent(cs, s->ev_released, 0));   // and the device side unread
+  int32_t* m = static_cast<int32_t*>(s->hmeta);
+  memset(m, 0, nmeta * 4);
+  s->frames = 0;
+  for (int b = 0; b < B; ++b) {
+    m[s->o_seq + b] = seq_len[b];
+    s->frames += seq_len[b];
+  }
+  if (labels) {
+    for (int b = 0; b < B; ++b) m[s->o_lablen + b] = label_len[b];
+    if (Lmax > 0) memcpy(m + s->o_labels, labels, (size_t)B * Lmax * 4);
+    // the label positions of every utterance sorted by class (counting sort): the fixed summation order of ctc_grad
+    std::vector<int32_t> fill((size_t)C);
+    for (int b = 0; b < B; ++b) {
+      int32_t* c0 = m + s->o_cstart + (size_t)b * (C + 1);
+      const int32_t* lb = labels + (size_t)b * Lmax;
+      for (int i = 0; i < label_len[b]; ++i) c0[lb[i] + 1] += 1;
+      for (int c = 0; c < C; ++c) c0[c + 1] += c0[c];
+      std::copy(c0, c0 + C, fill.begin());
+      for (int i = 0; i < label_len[b]; ++i) m[s->o_cpos + (size_t)b * Lm + fill[lb[i]]++] = i;
+    }
+  }
+  if (sr) {
+    // logits[t',b'] <- flat row q = b'*2T + t' of O = stack(fw,bw) [2,B,T,H];
+    // physical row index in the [(t*Bp+b)*2 + d][Hp] view of the last layer's output.
+    int32_t* map = m + s->o_rowmap;
+    for (size_t i = 0; i < (size_t)Tp * Bp; ++i) map[i] = -1;
+    for (int tp = 0; tp < Tp; ++tp)
+      for (int bq = 0; bq < B; ++bq) {
+        const int64_t q = (int64_t)bq * 2 * T + tp;
+        const int d = (int)(q / ((int64_t)B * T));
+        const int64_t rem = q % ((int64_t)B * T);
+        const int b = (int)(rem / T), t = (int)(rem % T);
+        map[(size_t)tp * Bp + bq] = (t * Bp + b) * 2 + d;
+      }
+  }
+  if (centre) {
+    const size_t nc = (size_t)B * T * ncep;
+    if (pinned_feats) {
+      memcpy(s->hfeats, centre, nc * 4);
+      memcpy(static_cast<float*>(s->hfeats) + nc, pad_value, (size_t)B * 4);
+      HIPCHK(h, hipMemcpyAsync(s->dfeats.p, s->hfeats, (nc + B) * 4, hipMemcpyHostToDevice, cs));
+    } else {
+      HIPCHK(h, hipMemcpyAsync(s->dfeats.p, centre, nc * 4, hipMemcpyHostToDevice, cs));
+      HIPCHK(h, hipMemcpyAsync(s->dfeats.as<float>() + nc, pad_value, (size_t)B * 4, hipMemcpyHostToDevice, cs));
+    }
+  } else if (pinned_feats) {
+    memcpy(s->hfeats, feats, nfeat * 4);
+    HIPCHK(h, hipMemcpyAsync(s->dfeats.p, s->hfeats, nfeat * 4, hipMemcpyHostToDevice, cs));
+  } else {
+    HIPCHK(h, hipMemcpyAsync(s->dfeats.p, feats, nfeat * 4, hipMemcpyHostToDevice, cs));
+  }
+  HIPCHK(h, hipMemcpyAsync(s->dmeta.p, s->hmeta, nmeta * 4, hipMemcpyHostToDevice, cs));
+  HIPCHK(h, hipEventRecord(s->ev_copy, cs));
+  s->copy_valid = true;
+  s->B = B; s->T = T; s->Lmax = labels ? Lmax : 0; s->Bp = Bp; s->Tp = Tp; s->ctx = ctx; s->ncep = ncep;
+  s->has_labels = labels != nullptr;
+  s->centre = centre != nullptr;
+  return NASR_OK;
+}
+
+// Makes the filled slot the resident batch: the compute stream waits for its copies, the previous resident slot is
+// released, and the features are laid out for the step (time-major rows, context windows, operand scales).
+int slot_commit(nasr_ctx* h, BatchSlot* s) {
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_shape(h, s->B, s->T, s->Lmax);
   if (rc) return rc;
-  const int Bp = h->Bp;
+  const int B = s->B, T = s->T, Bp = h->Bp;
+  {
+    std::lock_guard<std::mutex> lk(h->slot_mu);
+    if (h->cur && h->cur != s) {
+      // every kernel that reads the old batch's arrays is already on the compute stream: an event here releases them
+      (void)hipEventRecord(h->cur->ev_released, h->st);
+      h->cur->released_valid = true;
+      h->cur->state = SLOT_FREE;
+    }
+    s->state = SLOT_RESIDENT;
+    h->cur = s;
+  }
+  HIPCHK(h, hipStreamWaitEvent(h->st, s->ev_copy, 0));
+  int32_t* md = s->meta_d();
+  h->seq_p = md + s->o_seq; h->lablen_p = md + s->o_lablen; h->labels_p = md + s->o_labels;
+  h->cstart_p = md + s->o_cstart; h->cpos_p = md + s->o_cpos; h->rowmap_p = md + s->o_rowmap;
   h->ev_used = 0;
   h->spans.clear();
   if (h->profiling) {
@@ -674,55 +902,22 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
     h->total_valid = false;
   }
   h->h_seq.assign((size_t)Bp, 0);
-  h->frames = 0;
-  for (int b = 0; b < B; ++b) {
-    h->h_seq[b] = seq_len[b];
-    h->frames += seq_len[b];
-  }
+  const int32_t* hm = static_cast<const int32_t*>(s->hmeta);
+  for (int b = 0; b < B; ++b) h->h_seq[b] = hm[s->o_seq + b];
+  h->frames = s->frames;
   {
     PhaseScope ps(h, PH_PACK);
-    if (centre) {   // feats_bm is large enough: B*T*F >= B*T*numcep + B
-      HIPCHK(h, hipMemcpyAsync(h->feats_bm.p, centre, (size_t)B * T * ncep * 4, hipMemcpyHostToDevice, h->st));
-      HIPCHK(h, hipMemcpyAsync(h->feats_bm.as<float>() + (size_t)B * T * ncep, pad_value, (size_t)B * 4,
-                               hipMemcpyHostToDevice, h->st));
-    } else {
-      HIPCHK(h, hipMemcpyAsync(h->feats_bm.p, feats, (size_t)B * T * h->F * 4, hipMemcpyHostToDevice, h->st));
-    }
-    HIPCHK(h, hipMemcpyAsync(h->seq.p, h->h_seq.data(), (size_t)Bp * 4, hipMemcpyHostToDevice, h->st));
-    if (labels) {
-      std::vector<int32_t> ll((size_t)Bp, 0);
-      for (int b = 0; b < B; ++b) ll[b] = label_len[b];
-      if (Lmax > 0)
-        HIPCHK(h, hipMemcpyAsync(h->labels.p, labels, (size_t)B * Lmax * 4, hipMemcpyHostToDevice, h->st));
-      HIPCHK(h, hipMemcpyAsync(h->lablen.p, ll.data(), (size_t)Bp * 4, hipMemcpyHostToDevice, h->st));
-      HIPCHK(h, hipStreamSynchronize(h->st));  // ll is a stack-lifetime staging vector
-    }
-    if (h->cfg.merge == NASR_MERGE_STACK_RESHAPE && h->D == 2) {
-      // logits[t',b'] <- flat row q = b'*2T + t' of O = stack(fw,bw) [2,B,T,H];
-      // physical row index in the [(t*Bp+b)*2 + d][Hp] view of the last layer's output.
-      std::vector<int32_t> map((size_t)h->Tp * Bp, -1);
-      for (int tp = 0; tp < h->Tp; ++tp)
-        for (int bq = 0; bq < B; ++bq) {
-          const int64_t q = (int64_t)bq * 2 * T + tp;
-          const int d = (int)(q / ((int64_t)B * T));
-          const int64_t rem = q % ((int64_t)B * T);
-          const int b = (int)(rem / T), t = (int)(rem % T);
-          map[(size_t)tp * Bp + bq] = (t * Bp + b) * 2 + d;
-        }
-      HIPCHK(h, hipMemcpyAsync(h->rowmap.p, map.data(), map.size() * 4, hipMemcpyHostToDevice, h->st));
-      HIPCHK(h, hipStreamSynchronize(h->st));
-    }
-    if (centre)
-      launch_expand_context(h->feats_bm.as<float>(), h->feats_bm.as<float>() + (size_t)B * T * ncep, h->seq.as<int>(),
-                            h->X0.as<float>(), B, Bp, T, ctx, ncep, h->Fp, h->st);
+    if (s->centre)
+      launch_expand_context(s->dfeats.as<float>(), s->dfeats.as<float>() + (size_t)B * T * s->ncep, h->seq_p,
+                            h->X0.as<float>(), B, Bp, T, s->ctx, s->ncep, h->Fp, h->st);
     else
-      launch_pack_feats(h->feats_bm.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
+      launch_pack_feats(s->dfeats.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
     if (h->gemm_tp) {
       pl_scales(h, h->X0.as<float>(), T * Bp, h->Fp, h->Fp, &h->sc_x0r, &h->sc_x0c, h->st);
-      if (labels && h->npre == 0)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
+      if (s->has_labels && h->npre == 0)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
         pl_split(h, h->X0.as<float>(), nullptr, h->X0TTP.as<unsigned char>(), T * Bp, h->Fp, h->Fp, nullptr,
                  h->sc_x0c.sp(), nullptr, h->st);
-    } else if (h->gemm_bf16 && labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
+    } else if (h->gemm_bf16 && s->has_labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
       launch_transpose(h->X0.as<float>(), h->X0T.as<float>(), T * Bp, h->Fp, h->Fp, T * Bp, h->st);
     HIPCHK(h, hipGetLastError());
   }
@@ -730,6 +925,41 @@ int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_
   h->have_grads = false;
   h->have_fwd = false;
   h->have_decoded = false;
+  return NASR_OK;
+}
+
+// the synchronous upload of nasr_upload_batch / nasr_train_step / ...: fill on the compute stream, commit
+int upload(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_t* labels, const int32_t* label_len,
+           int B, int T, int Lmax, const float* centre = nullptr, const float* pad_value = nullptr, int ctx = 0,
+           int ncep = 0) {
+  BatchSlot* s = slot_acquire(h, false);
+  if (!s) return h->fail(NASR_ERR_STATE, "every batch slot holds a staged batch: commit or discard one first");
+  int rc = slot_fill(h, s, feats, seq_len, labels, label_len, B, T, Lmax, centre, pad_value, ctx, ncep, h->st, false);
+  if (!rc) rc = slot_commit(h, s);
+  if (rc && h->cur != s) slot_set_state(h, s, SLOT_FREE);
+  return rc;
+}
+
+BatchSlot* slot_of_ticket(nasr_ctx* h, int ticket) {
+  if (ticket < 0 || (ticket & 255) >= NSLOT) return nullptr;
+  BatchSlot* s = &h->slots[ticket & 255];
+  std::lock_guard<std::mutex> lk(h->slot_mu);
+  return (s->state == SLOT_STAGED && (int)(s->gen & 0x7fffff) == (ticket >> 8)) ? s : nullptr;
+}
+
+int stage(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_t* labels, const int32_t* label_len, int B,
+          int T, int Lmax, const float* centre, const float* pad_value, int ctx, int ncep, int* ticket) {
+  if (!ticket) return h->fail(NASR_ERR_ARG, "null ticket");
+  *ticket = -1;
+  BatchSlot* s = slot_acquire(h, true);
+  if (!s) return h->fail(NASR_ERR_STATE, "no free batch slot: commit or discard a staged batch first");
+  const int rc = slot_fill(h, s, feats, seq_len, labels, label_len, B, T, Lmax, centre, pad_value, ctx, ncep, h->cst, true);
+  if (rc) {
+    slot_set_state(h, s, SLOT_FREE);
+    return rc;
+  }
+  slot_set_state(h, s, SLOT_STAGED);
+  *ticket = (int)(s - h->slots) | (int)((s->gen & 0x7fffff) << 8);
   return NASR_OK;
 }
 
@@ -747,11 +977,11 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
     if (!bwd)
       launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->rec_f16 ? h->Ucinv + k * h->N4 : nullptr,
                               h->gates[l].as<float>(), h->cbuf[l].as<float>(),
-                              h->outb[l].as<float>(), h->seq.as<int>(), h->xch, h->pctl + 1 + l, h->perr, h->Gbase,
+                              h->outb[l].as<float>(), h->seq_p, h->xch, h->pctl + 1 + l, h->perr, h->Gbase,
                               h->cfg.forget_bias, st, true);
     else
       launch_lstm_persist_bwd(dm, h->Upb + k * h->imb, h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(),
-                              dout_of(h, l), h->seq.as<int>(), h->xch, h->pctl + 1 + h->L + l, h->perr, h->Gbase, st, true);
+                              dout_of(h, l), h->seq_p, h->xch, h->pctl + 1 + h->L + l, h->perr, h->Gbase, st, true);
     h->persist_used = true;
     HIPCHK(h, hipGetLastError());
     return NASR_OK;
@@ -768,7 +998,7 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
       for (int s = s0; s < s1; ++s)
         launch_lstm_fwd_step(dm, s, h->Uf + sU, hst + (s & 1) * hs, hst + ((s + 1) & 1) * hs,
                              h->gates[l].as<float>(), h->cbuf[l].as<float>(), h->outb[l].as<float>(),
-                             h->seq.as<int>(), h->cfg.forget_bias, st);
+                             h->seq_p, h->cfg.forget_bias, st);
     } else {
       if (s1 == h->T) {
         (void)hipMemsetAsync(par, 0, ps * 4, st);
@@ -778,7 +1008,7 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
         const int k = h->T - 1 - s;
         launch_lstm_bwd_step(dm, s, h->Ub + sU, par + (k & 1) * ps, par + ((k + 1) & 1) * ps,
                              h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(), dout_of(h, l),
-                             dcs + (k & 1) * hs, dcs + ((k + 1) & 1) * hs, h->seq.as<int>(), st);
+                             dcs + (k & 1) * hs, dcs + ((k + 1) & 1) * hs, h->seq_p, st);
       }
     }
   };
@@ -954,6 +1184,10 @@ int forward(nasr_ctx* h) {
   const int R = T * Bp;
   h->n_fwd_launch = 0;
   const int NC = h->pipe_chunks;
+  // the fault word of the pass that starts here (a training step or a forward-only call); what an unread earlier word
+  // said is gone with it
+  HIPCHK(h, hipMemsetAsync(h->Gbase, 0, GRAD_HEAD * 4, h->st));
+  h->adam_unverified = 0;
   // the control blocks of this pass's persistent launches, cleared in one go (one per layer: run_steps)
   if (h->persist) HIPCHK(h, hipMemsetAsync(h->pctl + 1, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
   for (int i = 0; i < h->npre; ++i) {
@@ -1011,7 +1245,7 @@ int forward(nasr_ctx* h) {
     g.C = h->logits.as<float>();
     g.M = h->Tp * Bp; g.N = h->Cp; g.K = h->Pinp;
     g.lda = sr ? Hp : h->Pinp; g.ldb = h->Cp; g.ldc = h->Cp;
-    g.a_map = sr ? h->rowmap.as<int>() : nullptr;
+    g.a_map = sr ? h->rowmap_p : nullptr;
     g.a_rows = sr ? 2 * R : R;
     g.bias = h->P + h->off_b;
     // N = Cp (32 for the 29 classes) gives the 128-row tiles of gemm.hip one block column: split K to fill the chip
@@ -1035,13 +1269,13 @@ CtcDims ctc_dims(nasr_ctx* h) {
 int ctc_forward(nasr_ctx* h) {
   PhaseScope ps(h, PH_PROJCTC);
   const CtcDims d = ctc_dims(h);
-  launch_ctc_logz(d, h->logits.as<float>(), h->seq.as<int>(), h->logz.as<float>(), h->st);
-  launch_ctc_alpha_beta(d, h->logits.as<float>(), h->logz.as<float>(), h->labels.as<int>(), h->lablen.as<int>(),
-                        h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->aoff.as<double>(),
+  launch_ctc_logz(d, h->logits.as<float>(), h->seq_p, h->logz.as<float>(), h->st);
+  launch_ctc_alpha_beta(d, h->logits.as<float>(), h->logz.as<float>(), h->labels_p, h->lablen_p,
+                        h->seq_p, h->alpha.as<float>(), h->beta.as<float>(), h->aoff.as<double>(),
                         h->boff.as<double>(), h->nll.as<float>(), h->logp.as<double>(), h->st);
   launch_mean(h->nll.as<float>(), h->B, h->loss.as<float>(), h->st);
   if (h->step_decode) {
-    launch_greedy(d, h->logits.as<float>(), h->seq.as<int>(), h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
+    launch_greedy(d, h->logits.as<float>(), h->seq_p, h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
                   h->st);
     h->have_decoded = true;
   }
@@ -1169,9 +1403,9 @@ int backward(nasr_ctx* h) {
   {
     PhaseScope ps(h, PH_PROJCTC);
     const CtcDims d = ctc_dims(h);
-    launch_ctc_grad(d, h->logits.as<float>(), h->logz.as<float>(), h->labels.as<int>(), h->lablen.as<int>(),
-                    h->seq.as<int>(), h->alpha.as<float>(), h->beta.as<float>(), h->aoff.as<double>(),
-                    h->boff.as<double>(), h->logp.as<double>(), 1.f / (float)h->B, h->st);
+    launch_ctc_grad(d, h->logits.as<float>(), h->logz.as<float>(), h->lablen_p, h->seq_p,
+                    h->cstart_p, h->cpos_p, h->alpha.as<float>(), h->beta.as<float>(),
+                    h->aoff.as<double>(), h->boff.as<double>(), h->logp.as<double>(), 1.f / (float)h->B, h->st);
     HIPCHK(h, hipGetLastError());
   }
   {
@@ -1183,7 +1417,7 @@ int backward(nasr_ctx* h) {
     g.C = h->G + h->off_w;
     g.M = h->Pinp; g.N = h->Cp; g.K = Rp;
     g.lda = sr ? Hp : h->Pinp; g.ldb = h->Cp; g.ldc = h->Cp;
-    g.a_col = true; g.a_map = sr ? h->rowmap.as<int>() : nullptr; g.a_rows = sr ? 2 * R : R;
+    g.a_col = true; g.a_map = sr ? h->rowmap_p : nullptr; g.a_rows = sr ? 2 * R : R;
     g.split_k = gemm_pick_split(g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
@@ -1196,7 +1430,7 @@ int backward(nasr_ctx* h) {
     x.C = h->has_post ? h->dYbuf[h->npre].as<float>() : dout_of(h, h->L - 1);
     x.M = Rp; x.N = h->Pinp; x.K = h->Cp;
     x.lda = h->Cp; x.ldb = h->Cp; x.ldc = sr ? Hp : h->Pinp;
-    x.b_col = true; x.a_rows = Rp; x.c_map = sr ? h->rowmap.as<int>() : nullptr; x.split_k = 1;
+    x.b_col = true; x.a_rows = Rp; x.c_map = sr ? h->rowmap_p : nullptr; x.split_k = 1;
     launch_gemm(x, h->st);
     HIPCHK(h, hipGetLastError());
   }
@@ -1209,17 +1443,21 @@ int backward(nasr_ctx* h) {
   const int NC = h->pipe_chunks;
   if (NC <= 1) {
     for (int l = h->L - 1; l >= 0; --l) {
+      const bool defer = h->persist && h->bucket_defer;
       {
         PhaseScope ps(h, PH_RECB);
         int rc = run_steps(h, l, true, 0, T, h->st);
         if (rc) return rc;
         h->n_bwd_launch += h->persist ? 1 : T;
       }
+      if (defer && l + 1 < h->L && h->bucket_of_layer[l + 1] >= 0)   // the layer above's bucket, held back over this launch
+        HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l + 1]], h->st));
       PhaseScope ps(h, PH_WGRAD);
       if (l > 0 || h->npre > 0) gemm_dx(h, l, 0, R, h->st, true);   // critical path first
       int rc = weight_grads(h, l);
       if (rc) return rc;
-      if (h->bucket_of_layer[l] >= 0) HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
+      if (h->bucket_of_layer[l] >= 0 && !(defer && l > 0))
+        HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
     }
   } else {
     // BPTT of layer l on chunk c needs dOut_l[chunk c] = dX GEMM of layer l+1's chunk c, and its own chunk c+1
@@ -1508,37 +1746,23 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       for (auto& e2 : h->ev_dx) (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
     }
   }
+  if (hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking) != hipSuccess) return bail(NASR_ERR_HIP, "hipStreamCreate (copy stream) failed");
+  for (BatchSlot& bs : h->slots)
+    if (hipEventCreateWithFlags(&bs.ev_copy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&bs.ev_released, hipEventDisableTiming) != hipSuccess)
+      return bail(NASR_ERR_HIP, "hipEventCreate failed");
   (void)hipEventCreate(&h->ev_total_a);
   (void)hipEventCreate(&h->ev_total_b);
   memset(&h->last_times, 0, sizeof(h->last_times));
   if (hipStreamSynchronize(h->st) != hipSuccess) return bail(NASR_ERR_HIP, "stream synchronize failed in create");
   if (h->persist) {
-    // Census: two steps of both persistent kernels on a zero layer.  A chip that does not place 32 workgroups on each of
-    // its 8 XCDs (partition modes, masked CUs, a co-tenant) is detected here and served by the per-step kernels.
-    const int Bp = 16, T = 2;
-    const size_t R = (size_t)T * Bp;
-    DevBuf g, c, o, dg, sq;
-    bool grew = false;
-    bool ok = g.ensure(R * h->D * h->N4 * 4, &grew) && c.ensure(R * h->D * h->Hp * 4, &grew) &&
-              o.ensure(R * h->D * h->Hp * 4, &grew) && dg.ensure(R * h->D * h->N4 * 4, &grew) && sq.ensure(Bp * 4, &grew);
-    if (ok) {
-      (void)hipMemsetAsync(g.p, 0, R * h->D * h->N4 * 4, h->st);
-      (void)hipMemsetAsync(o.p, 0, R * h->D * h->Hp * 4, h->st);
-      std::vector<int32_t> two((size_t)Bp, T);
-      (void)hipMemcpyAsync(sq.p, two.data(), Bp * 4, hipMemcpyHostToDevice, h->st);
-      const LstmDims dm{T, Bp, Bp, h->H, h->Hp, h->D};
-      launch_lstm_persist_fwd(dm, h->Upf, h->rec_f16 ? h->Ucinv : nullptr, g.as<float>(), c.as<float>(), o.as<float>(),
-                              sq.as<int>(), h->xch, h->pctl, h->perr, nullptr, 1.f, h->st);
-      launch_lstm_persist_bwd(dm, h->Upb, g.as<float>(), dg.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(),
-                              h->xch, h->pctl, h->perr, nullptr, h->st);
-      ok = hipStreamSynchronize(h->st) == hipSuccess && hipGetLastError() == hipSuccess && *h->perr == 0;
-    }
-    for (DevBuf* b : {&g, &c, &o, &dg, &sq}) b->release();
-    if (!ok) {
-      *h->perr = 0;
-      h->persist = false;
-    }
+    if (!persist_census(h)) h->persist = false;
     h->persist_ok = h->persist;
+    h->persist_wanted = h->persist;
+    const char* er = getenv("NASR_PERSIST_REARM");
+    h->rearm_after = er && *er ? std::max<long long>(0, atoll(er)) : 200;
+    const char* eb = getenv("NASR_BUCKET_DEFER");
+    h->bucket_defer = !(eb && eb[0] == '0');
   }
   *out = h;
   return NASR_OK;
@@ -1573,8 +1797,20 @@ int nasr_destroy(nasr_handle h) {
   for (nasr_ctx::SV* v : {&h->sc15, &h->sc_x0r, &h->sc_x0c, &h->sc_gr, &h->sc_gc}) v->release();
   for (auto* vec : {&h->sc_yr, &h->sc_yc, &h->sc_wr, &h->sc_wc, &h->sc_dr, &h->sc_dc})
     for (auto& v : *vec) v.release();
-  for (DevBuf* b : {&h->feats_bm, &h->X0, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
-                    &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->seq, &h->labels, &h->lablen, &h->rowmap, &h->slabs,
+  if (h->cst) {
+    (void)hipStreamSynchronize(h->cst);
+    (void)hipStreamDestroy(h->cst);
+  }
+  for (BatchSlot& bs : h->slots) {
+    bs.dfeats.release();
+    bs.dmeta.release();
+    if (bs.hfeats) (void)hipHostFree(bs.hfeats);
+    if (bs.hmeta) (void)hipHostFree(bs.hmeta);
+    if (bs.ev_copy) (void)hipEventDestroy(bs.ev_copy);
+    if (bs.ev_released) (void)hipEventDestroy(bs.ev_released);
+  }
+  for (DevBuf* b : {&h->X0, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
+                    &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
     b->release();
   for (auto* v : {&h->doutL, &h->hstateL, &h->partialL, &h->dcstateL, &h->dgL})
@@ -1682,6 +1918,37 @@ int nasr_upload_batch_context(nasr_handle h, const float* centre, const float* p
   return upload(h, nullptr, seq_len, labels, label_len, B, T, Lmax, centre, pad_value, numcontext, numcep);
 }
 
+int nasr_stage_batch(nasr_handle h, const float* feats, const int32_t* seq_len, const int32_t* labels,
+                     const int32_t* label_len, int B, int T, int Lmax, int* ticket) {
+  if (!h) return NASR_ERR_ARG;
+  return stage(h, feats, seq_len, labels, label_len, B, T, Lmax, nullptr, nullptr, 0, 0, ticket);
+}
+
+int nasr_stage_batch_context(nasr_handle h, const float* centre, const float* pad_value, int numcontext, int numcep,
+                             const int32_t* seq_len, const int32_t* labels, const int32_t* label_len, int B, int T,
+                             int Lmax, int* ticket) {
+  if (!h) return NASR_ERR_ARG;
+  if (!centre) return h->fail(NASR_ERR_ARG, "null input buffer");
+  return stage(h, nullptr, seq_len, labels, label_len, B, T, Lmax, centre, pad_value, numcontext, numcep, ticket);
+}
+
+int nasr_commit_batch(nasr_handle h, int ticket) {
+  if (!h) return NASR_ERR_ARG;
+  BatchSlot* s = slot_of_ticket(h, ticket);
+  if (!s) return h->fail(NASR_ERR_STATE, "nasr_commit_batch: no staged batch behind this ticket");
+  const int rc = slot_commit(h, s);
+  if (rc && h->cur != s) slot_set_state(h, s, SLOT_FREE);
+  return rc;
+}
+
+int nasr_discard_batch(nasr_handle h, int ticket) {
+  if (!h) return NASR_ERR_ARG;
+  BatchSlot* s = slot_of_ticket(h, ticket);
+  if (!s) return h->fail(NASR_ERR_STATE, "nasr_discard_batch: no staged batch behind this ticket");
+  slot_set_state(h, s, SLOT_FREE);
+  return NASR_OK;
+}
+
 int nasr_compute_grads(nasr_handle h) {
   if (!h) return NASR_ERR_ARG;
   if (!h->resident) return h->fail(NASR_ERR_STATE, "no resident batch");
@@ -1693,8 +1960,8 @@ int nasr_compute_grads(nasr_handle h) {
     h->window_open = true;
     h->total_valid = false;
   }
-  HIPCHK(h, hipMemsetAsync(h->Gbase, 0, GRAD_HEAD * 4, h->st));   // the step's fault word
-  int rc = forward(h);
+  persist_rearm(h);
+  int rc = forward(h);   // clears the step's fault word
   if (rc) return rc;
   rc = ctc_forward(h);
   if (rc) return rc;
@@ -1728,7 +1995,7 @@ int nasr_apply_adam(nasr_handle h, float grad_scale) {
   {
     PhaseScope ps(h, PH_ADAM);
     h->adam_step += 1;
-    h->adam_unverified += 1;
+    h->adam_unverified = 1;
     const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
     const double lr_t = (double)h->lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_step)) /
                         (1.0 - std::pow(b1, (double)h->adam_step));
@@ -1805,6 +2072,7 @@ int nasr_get_loss(nasr_handle h, float* loss_out) {
   HIPCHK(h, hipMemcpyAsync(&fault, h->Gbase, 4, hipMemcpyDeviceToHost, h->st));
   const int rc = sync_checked(h);
   if (fault != 0.f) {
+    // the word belongs to the LAST compute_grads: exactly one Adam launch (if any followed it) was a no-op
     h->adam_step -= std::min<int64_t>(h->adam_unverified, h->adam_step);
     h->adam_unverified = 0;
     if (rc) return rc;
@@ -1898,7 +2166,7 @@ int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len
   rc = forward(h);
   if (rc) return rc;
   const CtcDims d = ctc_dims(h);
-  launch_greedy(d, h->logits.as<float>(), h->seq.as<int>(), h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
+  launch_greedy(d, h->logits.as<float>(), h->seq_p, h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
                 h->st);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(lens_out, h->lens.p, (size_t)B * 4, hipMemcpyDeviceToHost, h->st));
@@ -1980,7 +2248,21 @@ int nasr_set_recurrence_mode(nasr_handle h, int persistent) {
     return h->fail(NASR_ERR_STATE, "the persistent recurrence is not available on this device / hidden size");
   HIPCHK(h, hipStreamSynchronize(h->st));
   h->persist = persistent != 0;
+  h->persist_wanted = h->persist;
   return repack(h);
+}
+
+int nasr_set_bucket_defer(nasr_handle h, int defer) {
+  if (!h) return NASR_ERR_ARG;
+  h->bucket_defer = defer != 0;
+  return NASR_OK;
+}
+
+int nasr_get_persist_stats(nasr_handle h, int* aborts, int* rearms) {
+  if (!h) return NASR_ERR_ARG;
+  if (aborts) *aborts = h->persist_aborts;
+  if (rearms) *rearms = h->persist_rearms;
+  return NASR_OK;
 }
 
 }  // extern "C"

@@ -85,34 +85,53 @@ class DataSet:
         return np.asarray(mfccs), np.asarray(labels), [s for _, _, s, _ in items], [n for _, _, _, n in items]
 
     # ------------------------------------------------------------------ asynchronous input pipeline
-    def prefetch(self, depth=2):
+    def prefetch(self, depth=2, stage=None):
         """Iterate the remaining batches of this epoch while a background thread unpickles and pads the next
         `depth` of them (the reference loads synchronously inside the timed loop, train.py:23-25).  Batch
         composition and order are exactly get_next_batch()'s; with rand_shift > 0 the augmentation draws from
-        np.random in the loader thread, so the draws stay in batch order."""
+        np.random in the loader thread, so the draws stay in batch order.  `stage` (optional): called with each
+        batch's four arrays in the loader thread as soon as it is padded - HipNetwork.stage_batch starts its H2D copy
+        there, under the step that is running (pinned staging + copy stream)."""
         import queue
         import threading
         q = queue.Queue(maxsize=max(1, depth))
-        stop = object()
+        done = object()
+        quit_ = threading.Event()                 # set when the consumer stops early (exception in a train step, close())
+
+        def put(item):
+            while not quit_.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def worker():
             try:
-                while self.has_more_batches():
-                    q.put(self.get_next_batch())
-                q.put(stop)
+                while not quit_.is_set() and self.has_more_batches():
+                    batch = self.get_next_batch()
+                    if stage is not None:
+                        stage(*batch)
+                    if not put(batch):
+                        return
+                put(done)
             except BaseException as exc:      # surface loader errors in the consumer
-                q.put(exc)
+                put(exc)
 
         t = threading.Thread(target=worker, name='nasr-prefetch', daemon=True)
         t.start()
-        while True:
-            item = q.get()
-            if item is stop:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            yield item
-        t.join()
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            quit_.set()
+            t.join()
 
     def get_feature_shape(self):
         return [self.config.batch_size, None, self.config.feature_size]

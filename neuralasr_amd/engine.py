@@ -173,27 +173,69 @@ class Engine:
         feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
         self._ck(self.lib.nasr_upload_batch(self.h, _fp(feats), _ip(seq), _ip(labels), _ip(ll), B, T, Lmax))
 
+    @staticmethod
+    def context_structure_ok(feats, seq, numcontext, numcep):
+        """True when feats [B,T,(2*numcontext+1)*numcep] is what include_context (utils.py:8-21) + one constant pad value
+        per utterance produce, so that the centre slice + the pad value determine it.  The first / last numcontext frames
+        of EVERY utterance are checked exactly: that is where an array that went through rand_shift's roll-and-crop
+        (dataset.py:23-31) differs (real neighbours instead of the pad value, and a pad read from a real sample); the
+        interior is spot-checked."""
+        B = feats.shape[0]
+        w = 2 * numcontext + 1
+        if numcontext < 1 or feats.shape[2] != w * numcep:
+            return False
+        pad = feats[:, 0, 0]
+        c0 = numcontext * numcep
+        rs = np.random.RandomState(0)
+        for b in range(B):
+            n = int(seq[b])
+            edge = sorted(set(range(min(numcontext, n))) | set(range(max(0, n - numcontext), n)))
+            t = np.asarray(edge + [rs.randint(n) for _ in range(4)], dtype=np.int64)
+            src = t[:, None] + np.arange(w) - numcontext                      # [E, w]: source frame of each slot
+            inside = (src >= 0) & (src < n)
+            want = np.where(inside[:, :, None], feats[b, np.clip(src, 0, n - 1), c0:c0 + numcep], pad[b])
+            if not np.array_equal(feats[b, t].reshape(len(t), w, numcep), want):
+                return False
+        return True
+
     def upload_batch_context(self, feats, seq_len, labels, label_len, numcontext, numcep):
         """Upload context-stacked features [B,T,(2*numcontext+1)*numcep] as their centre slice and rebuild the
         stacking on the device (include_context, utils.py:8-21).  Returns False (nothing uploaded) when the
         array does not have that structure (e.g. rand_shift cropped it), so the caller can upload it whole."""
         feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
-        w = 2 * numcontext + 1
-        if numcontext < 1 or feats.shape[2] != w * numcep:
+        if not self.context_structure_ok(feats, seq, numcontext, numcep):
             return False
         pad = np.ascontiguousarray(feats[:, 0, 0])
-        rs = np.random.RandomState(0)
-        for _ in range(48):                       # spot-check the window structure before trusting it
-            b = rs.randint(B)
-            t, k = rs.randint(seq[b]), rs.randint(w)
-            ts = t + k - numcontext
-            want = feats[b, ts, numcontext * numcep:(numcontext + 1) * numcep] if 0 <= ts < seq[b] else pad[b]
-            if not np.array_equal(feats[b, t, k * numcep:(k + 1) * numcep], np.broadcast_to(want, (numcep,))):
-                return False
         centre = np.ascontiguousarray(feats[:, :, numcontext * numcep:(numcontext + 1) * numcep])
         self._ck(self.lib.nasr_upload_batch_context(self.h, _fp(centre), _fp(pad), int(numcontext), int(numcep),
                                                     _ip(seq), _ip(labels), _ip(ll), B, T, Lmax))
         return True
+
+    def stage_batch(self, feats, seq_len, labels, label_len, numcontext=0, numcep=0):
+        """Copy the NEXT batch towards the GPU while the current step runs (pinned staging + the handle's copy stream,
+        include/nasr.h nasr_stage_batch); may be called from a loader thread.  With numcontext > 0 and features that have
+        include_context's structure only the centre slice crosses PCIe.  Returns a ticket for commit_batch(), or None
+        when no staging slot is free (upload the batch the synchronous way then)."""
+        from ctypes import c_int
+        feats, seq, labels, ll, B, T, Lmax = self._batch(feats, seq_len, labels, label_len)
+        ticket = c_int(-1)
+        if numcontext > 0 and self.context_structure_ok(feats, seq, numcontext, numcep):
+            pad = np.ascontiguousarray(feats[:, 0, 0])
+            centre = np.ascontiguousarray(feats[:, :, numcontext * numcep:(numcontext + 1) * numcep])
+            rc = self.lib.nasr_stage_batch_context(self.h, _fp(centre), _fp(pad), int(numcontext), int(numcep), _ip(seq),
+                                                   _ip(labels), _ip(ll), B, T, Lmax, byref(ticket))
+        else:
+            rc = self.lib.nasr_stage_batch(self.h, _fp(feats), _ip(seq), _ip(labels), _ip(ll), B, T, Lmax, byref(ticket))
+        if rc == _lib.NASR_ERR_STATE:
+            return None
+        self._ck(rc)
+        return int(ticket.value)
+
+    def commit_batch(self, ticket):
+        self._ck(self.lib.nasr_commit_batch(self.h, int(ticket)))
+
+    def discard_batch(self, ticket):
+        self._ck(self.lib.nasr_discard_batch(self.h, int(ticket)))
 
     def compute_grads(self):
         self._ck(self.lib.nasr_compute_grads(self.h))
@@ -298,6 +340,10 @@ class Engine:
             out.append((int(o.value), int(c.value)))
         return out
 
+    def set_bucket_defer(self, on):
+        """Hold each gradient bucket's event back over the next persistent BPTT launch (include/nasr.h)."""
+        self._ck(self.lib.nasr_set_bucket_defer(self.h, int(bool(on))))
+
     def bucket_wait(self, i, stream):
         """Makes HIP stream `stream` (raw handle) wait until the compute_grads() issued before has completed bucket i."""
         self._ck(self.lib.nasr_grad_bucket_wait(self.h, int(i), c_void_p(int(stream))))
@@ -323,6 +369,13 @@ class Engine:
     def recurrence_mode(self):
         """'persistent' (one launch per layer pass, lstm_persist.hip) or 'per-step' (lstm.hip)."""
         return 'persistent' if self.lib.nasr_get_recurrence_mode(self.h) else 'per-step'
+
+    def persist_stats(self):
+        """(aborts, re-arms) of the persistent recurrence on this handle (include/nasr.h, nasr_get_persist_stats)."""
+        from ctypes import c_int
+        a, r = c_int(), c_int()
+        self._ck(self.lib.nasr_get_persist_stats(self.h, byref(a), byref(r)))
+        return int(a.value), int(r.value)
 
     def set_recurrence_mode(self, persistent):
         self._ck(self.lib.nasr_set_recurrence_mode(self.h, int(bool(persistent))))

@@ -15,6 +15,8 @@ import glob
 import json
 import os
 import shutil
+import threading
+import weakref
 
 import numpy as np
 
@@ -75,6 +77,8 @@ class HipNetwork(Network):
         self.engine.set_params(self.initial_params(self.engine.tensors(), seed=1))
         self._grad_tensor = None
         self._reducer = None
+        self._staged = {}                       # id(mfccs) -> (ticket, weakref to mfccs): batches stage_batch() sent ahead
+        self._staged_lock = threading.Lock()
         self.global_step = self.config.start_step
         self.load_checkpoint(self.global_step if fortraining else 1, self.config.model_dir)
         if fortraining and self.coll.rank == 0:
@@ -149,19 +153,57 @@ class HipNetwork(Network):
             return n, [self.coll.rank]
         return n, list(range(n))
 
+    @staticmethod
+    def _is_abort(exc):
+        return 'persistent recurrence aborted' in str(exc) or 'training step is void' in str(exc)
+
+    def _retry_aborted(self, fn):
+        """Run fn(); if this rank's persistent recurrence gave up in it (the handle has then switched to the per-step
+        kernels, nasr_api.hip persist_check), run it once more.  Forward-only calls have no collective inside, so a
+        local repeat keeps multi-rank runs in step."""
+        from .._lib import NasrError
+        try:
+            return fn()
+        except NasrError as exc:
+            if not self._is_abort(exc):
+                raise
+            self.logger.warning('persistent recurrence aborted in a forward-only call: repeating it on the per-step kernels')
+            return fn()
+
     def _decode(self, mfccs, seq_len, which):
         if which == 'beam':
-            logits = self.engine.forward(mfccs, seq_len)
+            logits = self._retry_aborted(lambda: self.engine.forward(mfccs, seq_len))
             return self.engine.beam_search(logits, seq_len, self.beam_width, merge_repeated=True)[0]
-        return self.engine.greedy_decode(mfccs, seq_len)
+        return self._retry_aborted(lambda: self.engine.greedy_decode(mfccs, seq_len))
+
+    def _loss_ler_one(self, mfccs, labels, seq_len, labels_len):
+        def run():
+            loss, _ = self.engine.loss(mfccs, seq_len, labels, labels_len)
+            hyps = None if self.decoder == 'beam' else self.engine.get_decoded(len(seq_len), np.asarray(mfccs).shape[1])
+            return loss, hyps
+        loss, hyps = self._retry_aborted(run)
+        if hyps is None:
+            hyps = self._decode(mfccs, seq_len, 'beam')
+        return loss, self.engine.label_error_rate(hyps, labels, labels_len), hyps
 
     def _loss_ler(self, mfccs, labels, seq_len, labels_len):
-        loss, _ = self.engine.loss(mfccs, seq_len, labels, labels_len)
-        if self.decoder == 'beam':
-            hyps = self._decode(mfccs, seq_len, 'beam')
-        else:
-            hyps = self.engine.get_decoded(len(seq_len), np.asarray(mfccs).shape[1])
-        return loss, self.engine.label_error_rate(hyps, labels, labels_len), hyps
+        """(loss, mean LER, hypotheses).  A training network evaluates the way its graph was built
+        (setup_training_network, tfnetwork.py:115-140): per tower on the tf.split shards - the literal net's
+        stack-reshape map is a function of the SHARD's batch size - and the mean of the shard means."""
+        n, mine = self._towers()
+        if n == 1:
+            return self._loss_ler_one(mfccs, labels, seq_len, labels_len)
+        losses, lers, hyps = [], [], []
+        for k in mine:
+            f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, k)
+            lo, le, hy = self._loss_ler_one(f, l, s, ll)
+            losses.append(lo)
+            lers.append(le)
+            hyps.extend(hy)
+        loss, ler = float(np.mean(losses)), float(np.mean(lers))
+        if self.coll.world > 1:
+            loss, ler = self.coll.mean_scalars([loss, ler])
+        return loss, ler, hyps
 
     def train(self, mfccs, labels, seq_len, labels_len):
         self.global_step += 1
@@ -175,6 +217,50 @@ class HipNetwork(Network):
                                 % self.global_step)
         raise RuntimeError('training step %d stayed void after 3 attempts' % self.global_step)
 
+    def _use_device_context(self):
+        # rand_shift's roll-and-crop (dataset.py:23-31) leaves real neighbour frames where include_context put its pad
+        # in the first / last numcontext frames: such batches are uploaded whole
+        return (self.device_context and getattr(self.config, 'numcontext', 0) > 0 and
+                not getattr(self.config, 'rand_shift', 0) > 0)
+
+    # ------------------------------------------------------------------ input pipeline
+    def stage_batch(self, mfccs, labels, seq_len, labels_len):
+        """Send a batch that train() will be given NEXT towards the GPU now: this process's shard goes through pinned
+        memory and the engine's copy stream while the current step computes (the reference loads and feeds the next
+        batch inside the timed step, dataset.py:33-40, train.py:23-26).  Safe to call from DataSet.prefetch's loader
+        thread.  train() recognises the batch by identity; anything not staged is uploaded the synchronous way."""
+        n, mine = self._towers()
+        if len(mine) != 1:
+            return False                        # towers time-sliced on one GPU: each upload replaces the resident batch
+        f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, mine[0])
+        ctx = self.config.numcontext if self._use_device_context() else 0
+        ticket = self.engine.stage_batch(f, s, l, ll, ctx, getattr(self.config, 'numcep', 0))
+        if ticket is None:
+            return False
+        with self._staged_lock:
+            self._staged[id(mfccs)] = (ticket, weakref.ref(mfccs))
+        return True
+
+    def _take_staged(self, mfccs):
+        with self._staged_lock:
+            ent = self._staged.pop(id(mfccs), None)
+        if ent is None:
+            return None
+        if ent[1]() is not mfccs:               # the id was recycled by another array: the staged batch is an orphan
+            self.engine.discard_batch(ent[0])
+            return None
+        return ent[0]
+
+    def discard_staged(self):
+        """Give back the slots of batches that were staged but never trained on (the loop ended or raised)."""
+        with self._staged_lock:
+            ents, self._staged = list(self._staged.values()), {}
+        for ticket, _ in ents:
+            try:
+                self.engine.discard_batch(ticket)
+            except Exception:                   # noqa: BLE001 - already committed or discarded
+                pass
+
     def _train_once(self, mfccs, labels, seq_len, labels_len):
         from .._lib import NasrError
         n, mine = self._towers()
@@ -182,9 +268,11 @@ class HipNetwork(Network):
         reduced = False
         for k in mine:
             f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, k)
-            ctx = getattr(self.config, 'numcontext', 0)
-            if not (self.device_context and ctx > 0 and
-                    self.engine.upload_batch_context(f, s, l, ll, ctx, self.config.numcep)):
+            ticket = self._take_staged(mfccs) if len(mine) == 1 else None
+            if ticket is not None:
+                self.engine.commit_batch(ticket)
+            elif not (self._use_device_context() and
+                      self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
                 self.engine.upload_batch(f, s, l, ll)
             self.engine.compute_grads()
             if self.coll.world > 1 and self.bucketed_allreduce:
@@ -196,17 +284,22 @@ class HipNetwork(Network):
                 if self._reducer is not None:
                     self._reducer.all_reduce()
                     reduced = True
+            # Everything of this tower that reads the step's results sits inside the void handling: a rank whose
+            # persistent recurrence gave up must still reach every collective below (the other ranks are waiting in
+            # them); the step is repeated by train()
             try:
-                losses.append(self.engine.get_loss())
-            except NasrError as exc:            # keep the collective protocol going; the step is repeated by train()
-                if 'persistent recurrence aborted' not in str(exc) and 'training step is void' not in str(exc):
+                loss = self.engine.get_loss()
+                hyps = (self._decode(f, s, 'beam') if self.train_ler_decoder == 'beam'
+                        else self.engine.get_decoded(len(s), f.shape[1]))
+                ler = self.engine.label_error_rate(hyps, l, ll)
+            except NasrError as exc:
+                if not self._is_abort(exc):
                     raise
                 if self.coll.world == 1:
                     return None                 # single process: nothing else to keep in step, just repeat
-                losses.append(float('nan'))
-            hyps = (self._decode(f, s, 'beam') if self.train_ler_decoder == 'beam'
-                    else self.engine.get_decoded(len(s), f.shape[1]))
-            lers.append(self.engine.label_error_rate(hyps, l, ll))
+                loss, ler = float('nan'), float('nan')
+            losses.append(loss)
+            lers.append(ler)
             if len(mine) > 1:
                 g = self.engine.get_grads().astype(np.float64)
                 gsum = g if gsum is None else gsum + g

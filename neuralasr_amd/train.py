@@ -19,8 +19,9 @@ def train_model(dataTrain, datavalid, config, prefetch=2):
     logger.info('Label Dimensions: ' + str(dataTrain.get_label_shape()))
     network = config.load_network(fortraining=True)
     spent, loss_sum, ler_sum = 0.0, 0.0, 0.0     # train_time_sec is never reset (train.py:20,26,34)
+    stage = getattr(network, 'stage_batch', None)      # HipNetwork: the next batch's H2D copy runs under the current step
     for _ in range(config.epochs):
-        batches = dataTrain.prefetch(prefetch) if prefetch else iter(dataTrain.get_next_batch, None)
+        batches = dataTrain.prefetch(prefetch, stage=stage) if prefetch else iter(dataTrain.get_next_batch, None)
         while True:
             t0 = time.time()
             if not prefetch and not dataTrain.has_more_batches():
@@ -45,6 +46,8 @@ def train_model(dataTrain, datavalid, config, prefetch=2):
                     vloss, vler = network.validate(vm, vl, vs, vll)
                     logger.info('Valid: cost = %.4f' % vloss + ', ler = %.4f' % vler)
         dataTrain.reset_epoch()
+        if hasattr(network, 'discard_staged'):
+            network.discard_staged()
     logger.info('Finished training!!!')
     return network
 

@@ -55,6 +55,25 @@ def test_product_package_never_imports_the_oracle():
                 assert not c_use.search(open(src_path).read()), f'{f} includes oracle code'
 
 
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    """bench.py builds its workload, synthetic batch and weights itself; `oracle` appears only inside cpu_baseline()
+    and the Workload.oracle_spec() helper that leg calls."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, 'bench.py')).read())
+    allowed = {'cpu_baseline', 'oracle_spec'}
+
+    def visit(node, inside):
+        for child in ast.iter_child_nodes(node):
+            name = child.name if isinstance(child, (ast.FunctionDef, ast.ClassDef)) else None
+            now = inside or (name in allowed)
+            if isinstance(child, (ast.Import, ast.ImportFrom)):
+                mods = [a.name for a in child.names] if isinstance(child, ast.Import) else [child.module or '']
+                if any(m.split('.')[0] == 'oracle' for m in mods):
+                    assert inside, f'bench.py imports the oracle outside its cpu_baseline leg (line {child.lineno})'
+            visit(child, now)
+    visit(tree, False)
+
+
 def test_header_is_plain_c_and_links_from_c(tmp_path):
     """include/nasr.h compiles as C99, the struct layouts a C caller sees are the ones the ctypes binding assumes, and a C
     program linked against libnasr.so gets an error code (not a crash) from nasr_create when no GPU is usable."""

@@ -173,3 +173,79 @@ def test_shapes_change_between_steps(spec):
         assert loss == pytest.approx(lo, rel=3e-5), (B, T)
         assert rel(g, O.flatten(go)) < 1e-4, (B, T)
     e.close()
+
+
+def test_staged_batches_equal_synchronous_uploads_bitwise():
+    """nasr_stage_batch (pinned staging + copy stream, issued while a step is in flight) + nasr_commit_batch against
+    nasr_upload_batch: same loss, same gradients, bit for bit - for plain features, for the context form, for the
+    literal net's row map, with shapes changing from batch to batch; at most two batches ahead; discard returns a slot."""
+    from neuralasr_amd import utils
+    import threading
+    ctx, ncep = 2, 4
+    spec = O.ModelSpec((2 * ctx + 1) * ncep, 40, 1, True, 'stack_reshape', 7)
+    rs = np.random.RandomState(11)
+
+    def batch(B, T, seed):
+        _, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=seed, var_len=True, Lmin=1, Lmax=3)
+        feats = np.zeros((B, T, spec.feature_size), np.float32)
+        for b in range(B):
+            st = utils.include_context(rs.randn(int(seq_len[b]), ncep).astype(np.float32), ctx, ncep)
+            feats[b, :seq_len[b]] = ((st - st.mean()) / st.std()).astype(np.float32)
+        return feats, seq_len, labels, label_len
+    batches = [batch(5, 19, 1), batch(3, 31, 2), batch(8, 12, 3), batch(5, 19, 4)]
+    e, ref = engine_for(spec), engine_for(spec)
+    p0 = O.flatten(O.init_params(spec, seed=5))
+    e.set_params(p0)
+    ref.set_params(p0)
+
+    def ref_step(bt):
+        ref.upload_batch(*bt)
+        ref.compute_grads()
+        out = ref.get_loss(), ref.get_grads()
+        ref.apply_adam(1.0)
+        return out
+    want = [ref_step(bt) for bt in batches]
+    # batch 0 the synchronous way; while its step is in flight, batches 1 (plain) and 2 (context form) are staged from
+    # another thread; a third staged batch is refused; then they are committed in turn
+    e.upload_batch(*batches[0])
+    e.compute_grads()
+    tickets = {}
+
+    def loader():
+        tickets[1] = e.stage_batch(*batches[1])
+        tickets[2] = e.stage_batch(*batches[2], numcontext=ctx, numcep=ncep)
+        tickets[3] = e.stage_batch(*batches[3])
+    th = threading.Thread(target=loader)
+    th.start()
+    th.join()
+    assert tickets[1] is not None and tickets[2] is not None and tickets[3] is None
+    got = [(e.get_loss(), e.get_grads())]
+    e.apply_adam(1.0)
+    for k in (1, 2):
+        e.commit_batch(tickets[k])
+        if k == 2:
+            tickets[3] = e.stage_batch(*batches[3], numcontext=ctx, numcep=ncep)     # a slot is free again
+            assert tickets[3] is not None
+        e.compute_grads()
+        got.append((e.get_loss(), e.get_grads()))
+        e.apply_adam(1.0)
+    spare = e.stage_batch(*batches[0])
+    e.discard_batch(spare)
+    with pytest.raises(Exception, match='no staged batch'):
+        e.commit_batch(spare)
+    e.commit_batch(tickets[3])
+    e.compute_grads()
+    got.append((e.get_loss(), e.get_grads()))
+    e.apply_adam(1.0)
+    for (l1, g1), (l2, g2) in zip(got, want):
+        assert l1 == l2
+        np.testing.assert_array_equal(g1, g2)
+    np.testing.assert_array_equal(e.get_params(), ref.get_params())
+    # a validation batch in between (synchronous upload) always finds a slot, also with two batches staged
+    t1, t2 = e.stage_batch(*batches[1]), e.stage_batch(*batches[2])
+    assert t1 is not None and t2 is not None
+    assert e.loss(*batches[0])[0] == ref.loss(*batches[0])[0]
+    e.discard_batch(t1)
+    e.discard_batch(t2)
+    e.close()
+    ref.close()

@@ -204,7 +204,7 @@ def test_determinism_two_runs_bitwise():
     b = e.loss_and_grads(feats, seq_len, labels, label_len)
     assert a[0] == b[0]
     np.testing.assert_array_equal(a[1], b[1])
-    assert rel(a[2], b[2]) < 1e-6     # LDS float atomics in the CTC posterior bins may reorder
+    np.testing.assert_array_equal(a[2], b[2])     # every reduction of the step has a fixed order (no float atomics)
     e.close()
 
 

@@ -177,6 +177,51 @@ def test_aborted_persistent_launch_voids_the_step_and_falls_back(monkeypatch):
     e.close()
 
 
+def test_persistent_mode_is_rearmed_after_clean_steps(monkeypatch):
+    """After an abort the handle serves NASR_PERSIST_REARM clean steps on the per-step kernels, repeats the placement
+    census and returns to the persistent kernels (include/nasr.h, nasr_get_persist_stats); a second abort doubles the
+    wait.  The parameters follow the same trajectory as an undisturbed engine's throughout."""
+    from neuralasr_amd import _lib
+    spec = O.ModelSpec(12, 60, 2, True, 'concat', 7)
+    B, T = 6, 16
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=5, var_len=True, Lmin=1, Lmax=3)
+    start = O.flatten(rand_params(spec, 8)).astype(np.float32)
+    monkeypatch.setenv('NASR_PERSIST_REARM', '2')
+    e, ref = make_engine(spec, lr=1e-2), make_engine(spec, lr=1e-2)
+    e.set_params(start)
+    ref.set_params(start)
+    assert e.recurrence_mode == 'persistent' and e.persist_stats() == (0, 0)
+
+    def faulty_step():
+        monkeypatch.setenv('NASR_PERSIST_FAULT', '3')
+        with pytest.raises(_lib.NasrError, match='persistent recurrence aborted'):
+            e.train_step(feats, seq_len, labels, label_len)
+        monkeypatch.delenv('NASR_PERSIST_FAULT')
+
+    def good_step(mode):
+        loss = e.train_step(feats, seq_len, labels, label_len)
+        assert e.recurrence_mode == mode
+        assert loss == pytest.approx(ref.train_step(feats, seq_len, labels, label_len), rel=2e-5)
+
+    faulty_step()
+    assert e.recurrence_mode == 'per-step' and e.persist_stats() == (1, 0)
+    good_step('per-step')
+    good_step('per-step')
+    good_step('persistent')                       # the third step starts with the census and re-arms
+    assert e.persist_stats() == (1, 1)
+    good_step('persistent')
+    faulty_step()                                 # second abort: the wait doubles to 4 clean steps
+    assert e.persist_stats() == (2, 1)
+    for _ in range(4):
+        good_step('per-step')
+    good_step('persistent')
+    assert e.persist_stats() == (2, 2)
+    assert e.get_adam_state()[2] == ref.get_adam_state()[2] == 10
+    np.testing.assert_allclose(e.get_params(), ref.get_params(), rtol=0, atol=2e-4)
+    e.close()
+    ref.close()
+
+
 def test_fp16_plane_and_fp32_forward_recurrence_agree(monkeypatch):
     """The persistent forward recurrence keeps U as two fp16 planes and multiplies on v_mfma_f32_4x4x4_16B_f16 (three
     products per fp32 product, lstm_persist.hip); NASR_REC=f32 keeps fp32 planes and fp32 MFMAs.  Same logits, loss and

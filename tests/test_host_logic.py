@@ -151,3 +151,55 @@ def test_collective_without_process_group_offers_no_bucketed_reducer():
         def grad_buckets(self):
             return [(32, 10), (0, 32)]
     assert Collective().bucketed(FakeEngine(), None) is None
+
+
+def test_context_structure_check_refuses_every_rand_shift_crop():
+    """rand_shift's roll-and-crop (dataset.py:23-31) breaks include_context's window structure only in the
+    first / last numcontext frames of an utterance (real neighbours where the pad value was, a pad read from a real
+    sample): a sampled check passed 98 % of such batches.  The edge frames are now checked exactly."""
+    from neuralasr_amd.engine import Engine
+    from neuralasr_amd.utils import include_context
+    ctx, ncep, B = 10, 26, 16
+    rs = np.random.RandomState(3)
+    refused = 0
+    for trial in range(40):
+        T = 120
+        feats = np.zeros((B, T, (2 * ctx + 1) * ncep), np.float32)
+        seq = np.zeros(B, np.int32)
+        shifted = trial % 2 == 1
+        for b in range(B):
+            n = rs.randint(60, T + 1)
+            st = include_context(rs.randn(n, ncep).astype(np.float32), ctx, ncep)
+            st = ((st - st.mean()) / st.std()).astype(np.float32)
+            if shifted and b == trial % B:                      # one utterance of the batch went through augment_mfcc
+                r = [-2, -1, 1, 2][(trial // 2) % 4]
+                st = np.roll(st, r, axis=0)
+                st = st[r:] if r > 0 else st[:r]
+            seq[b] = st.shape[0]
+            feats[b, :seq[b]] = st
+        ok = Engine.context_structure_ok(feats, seq, ctx, ncep)
+        assert ok == (not shifted), (trial, ok)
+        refused += not ok
+    assert refused == 20
+    assert not Engine.context_structure_ok(feats[:, :, :-1], seq, ctx, ncep)      # wrong width
+
+
+def test_prefetch_worker_stops_when_the_consumer_walks_away(tmp_path):
+    """An abandoned prefetch generator (a train step raised) must release its loader thread."""
+    import threading
+    import time
+    from neuralasr_amd.config import Config
+    from neuralasr_amd.dataset import DataSet
+    samples = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sample_set')
+    lines = open(os.path.join(samples, 'toy.config')).read().replace('batch_size=2', 'batch_size=1')
+    cfgp = tmp_path / 'toy.config'
+    cfgp.write_text('\n'.join(('output=' + samples) if ln.startswith('output=') else ln for ln in lines.splitlines()) + '\n')
+    cfg = Config(str(cfgp), True)
+    ds = DataSet(cfg.train_input, cfg)
+    gen = ds.prefetch(depth=1)
+    next(gen)
+    gen.close()                                   # consumer stops after one batch: the queue is full, the worker blocked
+    deadline = time.time() + 5.0
+    while time.time() < deadline and any(t.name == 'nasr-prefetch' and t.is_alive() for t in threading.enumerate()):
+        time.sleep(0.05)
+    assert not any(t.name == 'nasr-prefetch' and t.is_alive() for t in threading.enumerate())
