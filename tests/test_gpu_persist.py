@@ -216,7 +216,7 @@ def test_persistent_mode_is_rearmed_after_clean_steps(monkeypatch):
         good_step('per-step')
     good_step('persistent')
     assert e.persist_stats() == (2, 2)
-    assert e.get_adam_state()[2] == ref.get_adam_state()[2] == 10
+    assert e.get_adam_state()[2] == ref.get_adam_state()[2] == 9
     np.testing.assert_allclose(e.get_params(), ref.get_params(), rtol=0, atol=2e-4)
     e.close()
     ref.close()
