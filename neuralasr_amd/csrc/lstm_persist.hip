@@ -235,7 +235,8 @@ constexpr int LDS_RED = 0, LDS_ADG = 2 * 4 * 4 * 64, LDS_SIDE = LDS_ADG + 2 * 25
 // in an MFMA wave right after the publish 1.64 (they compete with the hand-off), none at all 1.46.
 
 // F16: the recurrent product runs on v_mfma_f32_4x4x4_16B_f16 - U as two fp16 planes under per-column scales (register
-// footprint unchanged), h (|h| < 1) split into two fp16 parts of h * 2^14 once per step, three MFMAs per chunk of 4 units
+// footprint unchanged), h (|h| < 1) split into two fp16 parts of h * 2^14 once per step BY ITS PRODUCER (they travel
+// packed in the 4 bytes the fp32 value took), three MFMAs per chunk of 4 units
 // (h1 U1 + h1 U2 + h2 U1) instead of four fp32 ones: 96 instead of 128 MFMAs of the same duration per wave and step,
 // the same accuracy class as the fp16-plane GEMMs.  cinv [D][N4]: 1 / column scale.
 template <int NU, bool F16>
@@ -364,16 +365,19 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
         if (s > 0 && ok) {
           // 3. acc[.][utt] (16 units x 4 gates) += h[utt][k] * U[k][cols]; A broadcast from block bb%16
           if constexpr (F16) {
+            // the producer published each h as its two fp16 parts in one word (low half a1, high half a2): gather the
+            // four a1 / a2 of this lane's chunk with two byte permutes each
             h4 a1[NJ], a2[NJ];
 #pragma unroll
-            for (int i = 0; i < NJ; ++i)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float v = P[i][r] * 16384.f;
-                const _Float16 h1 = (_Float16)v;
-                a1[i][r] = h1;
-                a2[i][r] = (_Float16)(v - (float)h1);
-              }
+            for (int i = 0; i < NJ; ++i) {
+              typedef unsigned u2 __attribute__((ext_vector_type(2)));
+              const unsigned d0 = __float_as_uint(P[i][0]), d1 = __float_as_uint(P[i][1]);
+              const unsigned d2 = __float_as_uint(P[i][2]), d3 = __float_as_uint(P[i][3]);
+              const u2 lo = {__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u)};
+              const u2 hi = {__builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
+              a1[i] = __builtin_bit_cast(h4, lo);
+              a2[i] = __builtin_bit_cast(h4, hi);
+            }
             static_for<0, NCH>([&](auto bbc) {
               constexpr int bb = decltype(bbc)::value;
               acc[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a2[bb / 16], w1[bb], acc[0], 4, bb % 16, 0);
@@ -440,7 +444,18 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
             c = c * act.z + act.x * act.y;
             h = ptanh(c) * act.w;
           }
-          ghx[(size_t)par * Hp * 4 + hidx] = h;          // plain store: lands in this XCD's L2
+          if constexpr (F16) {
+            // split h (|h| < 1) into its two fp16 parts of h * 2^14 HERE, once, instead of in every consumer wave of the
+            // group (32 CUs x 4 waves redid these five operations per value on their MFMA chain): same arithmetic, same bits
+            const float v = h * 16384.f;
+            const _Float16 h1 = (_Float16)v;
+            const _Float16 h2 = (_Float16)(v - (float)h1);
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, h1) |
+                                ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+            ghx[(size_t)par * Hp * 4 + hidx] = __uint_as_float(pk);
+          } else {
+            ghx[(size_t)par * Hp * 4 + hidx] = h;          // plain store: lands in this XCD's L2
+          }
           float* sp = side + (par * 64 + lane) * 8;
           *reinterpret_cast<f32x4*>(sp) = act;
           *reinterpret_cast<float2*>(sp + 4) = make_float2(c, h);

