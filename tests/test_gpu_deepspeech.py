@@ -135,3 +135,79 @@ def test_reference_shape_constructs_and_steps():
     l2 = e.train_step(feats, seq_len, labels, label_len)
     assert np.isfinite([l0, l1, l2]).all() and l2 < l0
     e.close()
+
+
+def _reference_spec():
+    from neuralasr_amd.networks.deepspeech import DeepSpeech
+    return O.ModelSpec(546, DeepSpeech.n_cell_dim, 1, True, 'concat', 29, pre=DeepSpeech.pre_widths(), post=DeepSpeech.n_hidden,
+                       relu_clip=DeepSpeech.relu_clip, dropout=DeepSpeech.dropout)
+
+
+def _params_away_from_kinks(spec, seed):
+    """Weights of networks/deepspeech.py's shapes whose clipped-ReLU pre-activations sit at 4 +- ~0.5 (biases 4, weight
+    scales set from the input moments): 10^7 pre-activations at the reference's widths, none within reach of a kink, so the
+    fp32 path and the fp64 oracle take the same ReLU masks and can be compared to rounding.  (With natural weights a
+    handful of the 10^7 land within fp32 rounding of 0 and each flipped mask element moves its layer's gradient by
+    sqrt(1/N): see the second half of the test.)"""
+    rs = np.random.RandomState(seed)
+    params = []
+    second_moment = {'h1': 1.0, 'h2': 17.0, 'h3': 17.0, 'h5': 0.1}
+    for name, shp in spec.param_shapes():
+        if name in second_moment:
+            params.append(rs.randn(*shp) * 0.5 / np.sqrt(shp[0] * second_moment[name]))
+        elif name in ('b1', 'b2', 'b3', 'b5'):
+            params.append(np.full(shp, 4.0))
+        elif name.endswith('kernel'):
+            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+            k = rs.uniform(-lim, lim, size=shp)
+            k[:shp[0] - spec.hidden] *= 0.15                     # the input rows see activations of magnitude 4
+            params.append(k)
+        elif name == 'h6':
+            params.append(rs.randn(*shp) * np.sqrt(2.0 / (shp[0] + shp[1])))
+        else:
+            params.append(np.zeros(shp))
+    return [p.astype(np.float32).astype(np.float64) for p in params]
+
+
+def test_reference_widths_match_the_oracle():
+    """BASELINE.json configs[3] per GPU: networks/deepspeech.py at its own widths (546 -> 2048 / 2048 / 4096 -> BiLSTM 2048
+    -> 2048 -> 29), batch 32, dropout 0.05, against the fp64 oracle on a short ragged batch (T = 32: the oracle needs
+    ~20 s here; the widths, not T, are what the smaller cases leave untested - 64-tile GEMMs, split-K weight gradients
+    over 2048 / 4096-wide stages, the per-step recurrence kernels at Hp = 2048)."""
+    spec = _reference_spec()
+    B, T = 32, 32
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=5, var_len=True, Lmin=2, Lmax=6)
+    seed, counter = 4567, 3
+    params = _params_away_from_kinks(spec, 2)
+    assert O.deepspeech_kink_margin(spec, params, feats, seq_len, drop=(seed, counter)) > 1e-2
+    e = make_engine(spec)
+    e.set_params(O.flatten(params))
+    loss_o, nll_o, grads_o, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len,
+                                                                drop=(seed, counter))
+    e.set_dropout_state(seed, counter)
+    logits = e.forward(feats, seq_len)
+    np.testing.assert_allclose(logits, logits_o, atol=1e-4 * max(1.0, np.abs(logits_o).max()))
+    e.set_dropout_state(seed, counter)
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert loss == pytest.approx(loss_o, rel=2e-5)
+    np.testing.assert_allclose(nll, nll_o, rtol=2e-5)
+    scale = np.linalg.norm(O.flatten(grads_o))
+    worst = 0.0
+    for (name, off, r, c), g_o in zip(e.tensors(), grads_o):
+        g = grads[off:off + r * c].reshape(g_o.shape)
+        err = np.linalg.norm(g - g_o) / (np.linalg.norm(g_o) + 1e-2 * scale / np.sqrt(len(grads_o)))
+        worst = max(worst, err)
+        assert err <= 1e-4, (name, err)
+    # the same net with the reference's own initialisation (zero biases: pre-activations straddle the ReLU kink): the
+    # forward pass is continuous across it - logits and loss to the usual tolerance; a gradient tensor may differ by the
+    # few mask elements (of 10^7) that fp32 rounding decides the other way
+    params = [p.astype(np.float32).astype(np.float64) for p in O.init_params(spec, seed=3)]
+    e.set_params(O.flatten(params))
+    loss_o, nll_o, grads_o, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len,
+                                                                drop=(seed, counter))
+    e.set_dropout_state(seed, counter)
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert loss == pytest.approx(loss_o, rel=5e-5)
+    g_o = O.flatten(grads_o)
+    assert np.linalg.norm(grads - g_o) <= 1e-2 * np.linalg.norm(g_o)
+    e.close()
