@@ -257,10 +257,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--per-step', action='store_true', help='per-timestep launches (lstm.hip) instead of the persistent recurrence')
-    ap.add_argument('--allreduce', default='auto', choices=['auto', 'bucketed', 'bucketed-eager', 'single'],
+    ap.add_argument('--allreduce', default='auto', choices=['auto', 'bucketed', 'bucketed-eager', 'single', 'lib'],
                     help='N > 1: gradient exchange as one all-reduce after the backward pass (single), or per-layer buckets '
                          'on a side stream under the rest of the backward pass, each released after the next persistent '
-                         'BPTT launch (bucketed) or as soon as it is complete (bucketed-eager); auto times all during warm-up')
+                         'BPTT launch (bucketed) or as soon as it is complete (bucketed-eager); auto times these three during '
+                         'warm-up; lib = the same buckets through the library\'s own RCCL communicator (nasr_comm_*), opt-in')
     args = ap.parse_args()
 
     import torch
@@ -312,7 +313,13 @@ def main():
     gt = eng.grad_tensor() if use_dist else None
 
     reducer = None
-    if use_dist and world > 1 and args.allreduce != 'single':
+    if use_dist and world > 1 and args.allreduce == 'lib':
+        # the library's own communicator: rank 0's ncclUniqueId goes round by torch.distributed (a C host would use
+        # MPI_Bcast or a file), the collectives themselves are issued inside libnasr
+        box = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(box[0], rank, world)
+    elif use_dist and world > 1 and args.allreduce != 'single':
         try:                                  # the same code on every rank: a failure here is a failure everywhere
             from neuralasr_amd.parallel import BucketedAllReduce
             reducer = BucketedAllReduce(eng, dist, gt)
@@ -321,6 +328,8 @@ def main():
             reducer = None
     can_bucket = reducer is not None and len(reducer.views) > 1
     ar_mode = (args.allreduce if args.allreduce != 'auto' else 'bucketed') if can_bucket else 'single'
+    if args.allreduce == 'lib' and use_dist and world > 1:
+        ar_mode = 'lib'
 
     def set_mode(mode):
         eng.set_bucket_defer(mode != 'bucketed-eager')
@@ -328,7 +337,9 @@ def main():
     def step():
         eng.compute_grads()
         if use_dist:
-            if ar_mode != 'single':
+            if ar_mode == 'lib':
+                eng.comm_allreduce_grads()
+            elif ar_mode != 'single':
                 reducer.all_reduce()
             else:
                 dist.all_reduce(gt, op=dist.ReduceOp.SUM)

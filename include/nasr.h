@@ -171,6 +171,23 @@ int nasr_stage_batch_context(nasr_handle h, const float* centre, const float* pa
 int nasr_commit_batch(nasr_handle h, int ticket);
 int nasr_discard_batch(nasr_handle h, int ticket);   /* give a staged batch's slot back unused */
 int nasr_compute_grads(nasr_handle h);          /* forward+CTC+backward on the resident batch (async) */
+/* ---- in-library gradient exchange: average_gradients (tfnetwork.py:72-86) for hosts without torch.distributed ------
+ * One RCCL rank per handle (one process per GPU, or one host thread per handle).  librccl.so is bound with dlopen when
+ * the first of these calls is made.  Rank 0 calls nasr_comm_unique_id and hands the 128 bytes to the other ranks by
+ * the host's own means (MPI_Bcast, a file, a socket); every rank then calls nasr_comm_init (it blocks until all have
+ * joined).  Per step:  nasr_compute_grads(h); nasr_comm_allreduce_grads(h); nasr_apply_adam(h, 1.f / nranks);
+ * nasr_comm_allreduce_grads enqueues one sum all-reduce per gradient bucket on the handle's communication stream, each
+ * behind its bucket's completion event (so the upper layers' gradients cross xGMI under the backward pass of the layers
+ * below), and makes the handle's stream wait for the last one: no host synchronisation.  The step's fault word travels
+ * in the last bucket, so a void step (nasr_step_void) is void on every rank.  nasr_comm_mean averages a few host floats
+ * over the ranks (the reduce_mean of loss / LER at tfnetwork.py:135-136); without a communicator it leaves them as
+ * they are. */
+int nasr_comm_unique_id(void* id128);
+int nasr_comm_init(nasr_handle h, const void* id128, int rank, int nranks);
+int nasr_comm_size(nasr_handle h);
+int nasr_comm_allreduce_grads(nasr_handle h);
+int nasr_comm_mean(nasr_handle h, float* vals, int n);
+int nasr_comm_destroy(nasr_handle h);
 /* In persistent mode bucket i's event is held back over the NEXT persistent BPTT launch (the layer below's), so that
  * a collective released by nasr_grad_bucket_wait co-runs with that layer's GEMM phase rather than with a launch whose
  * hand-offs want every CU's memory queue to themselves (default on, NASR_BUCKET_DEFER=0 at create); 0 records every

@@ -28,7 +28,8 @@ SYMBOLS = [
     'nasr_set_profiling', 'nasr_get_phase_times', 'nasr_set_graph_mode',
     'nasr_get_recurrence_mode', 'nasr_set_recurrence_mode', 'nasr_set_dropout_state', 'nasr_get_dropout_state',
     'nasr_step_void', 'nasr_get_persist_stats', 'nasr_stage_batch', 'nasr_stage_batch_context', 'nasr_commit_batch',
-    'nasr_discard_batch', 'nasr_set_bucket_defer',
+    'nasr_discard_batch', 'nasr_set_bucket_defer', 'nasr_comm_unique_id', 'nasr_comm_init', 'nasr_comm_size',
+    'nasr_comm_allreduce_grads', 'nasr_comm_mean', 'nasr_comm_destroy',
 ]
 
 
@@ -124,6 +125,12 @@ def load():
         'nasr_commit_batch': (c_int, [H, c_int]),
         'nasr_discard_batch': (c_int, [H, c_int]),
         'nasr_set_bucket_defer': (c_int, [H, c_int]),
+        'nasr_comm_unique_id': (c_int, [c_void_p]),
+        'nasr_comm_init': (c_int, [H, c_void_p, c_int, c_int]),
+        'nasr_comm_size': (c_int, [H]),
+        'nasr_comm_allreduce_grads': (c_int, [H]),
+        'nasr_comm_mean': (c_int, [H, fp, c_int]),
+        'nasr_comm_destroy': (c_int, [H]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

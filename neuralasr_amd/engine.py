@@ -340,6 +340,34 @@ class Engine:
             out.append((int(o.value), int(c.value)))
         return out
 
+    # ------------------------------------------------------------------ in-library RCCL exchange (include/nasr.h nasr_comm_*)
+    def comm_unique_id(self):
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.nasr_comm_unique_id(buf)
+        if rc != 0:
+            msg = self.lib.nasr_last_error(None)
+            raise _lib.NasrError(rc, msg.decode() if msg else 'nasr_comm_unique_id failed')
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        assert len(unique_id) == 128
+        self._ck(self.lib.nasr_comm_init(self.h, ctypes.c_char_p(bytes(unique_id)), int(rank), int(nranks)))
+
+    def comm_size(self):
+        return int(self.lib.nasr_comm_size(self.h))
+
+    def comm_allreduce_grads(self):
+        self._ck(self.lib.nasr_comm_allreduce_grads(self.h))
+
+    def comm_mean(self, values):
+        v = np.ascontiguousarray(values, np.float32).copy()
+        self._ck(self.lib.nasr_comm_mean(self.h, _fp(v), v.size))
+        return v.tolist()
+
+    def comm_destroy(self):
+        self._ck(self.lib.nasr_comm_destroy(self.h))
+
     def set_bucket_defer(self, on):
         """Hold each gradient bucket's event back over the next persistent BPTT launch (include/nasr.h)."""
         self._ck(self.lib.nasr_set_bucket_defer(self.h, int(bool(on))))

@@ -360,3 +360,40 @@ def test_overfits_a_fixed_batch_to_zero_label_error():
     assert e.beam_search(logits, seq_len, 100, merge_repeated=False)[0] == truth
     assert e.label_error_rate(truth, labels, label_len) == 0.0
     e.close()
+
+
+def test_in_library_rccl_exchange_at_world_one():
+    """nasr_comm_* (include/nasr.h): a communicator of one rank bound through dlopen'ed librccl; the data-parallel step
+    compute_grads -> comm_allreduce_grads (one ncclAllReduce per bucket on the communication stream, behind the bucket
+    events) -> apply_adam(1/n) leaves the same parameters as the plain step, bit for bit; comm_mean of one rank is the
+    identity; a second init is refused."""
+    from neuralasr_amd import _lib
+    from neuralasr_amd.engine import Engine
+    spec = O.ModelSpec(20, 48, 3, True, 'concat', 9)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 6, 25, seed=3, var_len=True, Lmin=1, Lmax=4)
+    p0 = O.flatten(O.init_params(spec, seed=4))
+    a = Engine(20, 48, 3, True, 'concat', 9, learning_rate=1e-2)
+    b = Engine(20, 48, 3, True, 'concat', 9, learning_rate=1e-2)
+    a.set_params(p0)
+    b.set_params(p0)
+    assert a.comm_size() == 1
+    uid = a.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    a.comm_init(uid, 0, 1)
+    with pytest.raises(_lib.NasrError, match='already has a communicator'):
+        a.comm_init(uid, 0, 1)
+    assert len(a.grad_buckets()) == 3
+    for _ in range(3):
+        a.upload_batch(feats, seq_len, labels, label_len)
+        a.compute_grads()
+        a.comm_allreduce_grads()
+        a.apply_adam(1.0 / a.comm_size())
+        la = a.get_loss()
+        lb = b.train_step(feats, seq_len, labels, label_len)
+        assert la == lb
+    np.testing.assert_array_equal(a.get_params(), b.get_params())
+    assert a.comm_mean([la, 0.25]) == pytest.approx([la, 0.25])
+    a.comm_destroy()
+    assert a.comm_size() == 1
+    a.close()
+    b.close()
