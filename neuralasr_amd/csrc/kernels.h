@@ -146,6 +146,9 @@ struct PersistCtl {            // device words, zeroed before every launch
   unsigned error;              // bit 0: a bounded spin gave up, bit 1: placement is not 32 workgroups on each of 8 XCDs
   unsigned pad[23];
   unsigned flags[8 * 128];     // per group: forward 32 words (one per member), BPTT 128 (member*4 + wave)
+#if defined(NASR_PSTAMP) && NASR_PSTAMP
+  unsigned stamps[256][12];    // diagnostic build only (tools/persistbench): wave 0's phase cycles of EVERY workgroup
+#endif
 };
 bool persist_supported(int Hp);
 size_t persist_image_floats(int Hp, bool bwd);   // floats of one direction's operand image

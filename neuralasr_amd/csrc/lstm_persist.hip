@@ -63,10 +63,13 @@ struct Stamps {
     }
 #endif
   }
-  __device__ __forceinline__ void flush(PersistCtl* ctl) {
+  __device__ __forceinline__ void flush(PersistCtl* ctl, unsigned slot, bool first) {
 #if NASR_PSTAMP
-    if (on && (threadIdx.x & 63) == 0)
-      for (int i = 0; i < 12; ++i) ctl->pad[i] = acc[i];
+    if (on && (threadIdx.x & 63) == 0) {
+      for (int i = 0; i < 12; ++i) ctl->stamps[slot & 255][i] = acc[i];
+      if (first)
+        for (int i = 0; i < 12; ++i) ctl->pad[i] = acc[i];
+    }
 #endif
   }
 };
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
   const int hidx = (j >> 2) * 16 + q * 4 + (j & 3);
   bool aborted = false;
   Stamps stp;
-  stp.start(w == 0 && xcc == 0 && member == 0);
+  stp.start(w == 0);
 
   for (int rd = 0; rd < gm.rounds; ++rd) {
     const int b0 = (rd * NGD + grp) * gm.ub;
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
     __syncthreads();                  // the last cell update's results are in LDS
     if (w == 4) store_side(T - 1);
   }
-  stp.flush(ctl);
+  stp.flush(ctl, xcc * 32 + member, xcc == 0 && member == 0);
   if (aborted && tid == 0) raise_error(ctl, sticky, gm.fault, 1u);
 }
 
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
   const int jcl = j < Hp ? j : Hp - 1;
   bool aborted = false;
   Stamps stp;
-  stp.start(w == 0 && xcc == 0 && member == 0);
+  stp.start(w == 0);
 
   for (int rd = 0; rd < gm.rounds; ++rd) {
     const int b0 = (rd * NGD + grp) * gm.ub;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
     if (aborted) break;
     __syncthreads();                  // pfb / adg are reused by the next round
   }
-  stp.flush(ctl);
+  stp.flush(ctl, xcc * 32 + member, xcc == 0 && member == 0);
   if (aborted && tid == 0) raise_error(ctl, sticky, gm.fault, 1u);
 }
 

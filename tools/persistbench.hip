@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/persistbench.hip neuralasr_amd/csrc/lstm.hip neuralasr_amd/csrc/lstm_persist.hip -o tools/sb_persist
 //   tools/sb_persist [H=500] [B=16] [T=500] [D=2] [ragged=1]
 #include "../neuralasr_amd/csrc/kernels.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -126,6 +127,22 @@ int main(int argc, char** argv) {
       printf("   barrier arrival after wave 0 (cycles): w1 %.0f  w2 %.0f  w3 %.0f  mem %.0f\n", (int)hc.pad[7] / (double)T, (int)hc.pad[8] / (double)T,
              (int)hc.pad[9] / (double)T, (int)hc.pad[10] / (double)T);
     }
+#if defined(NASR_PSTAMP) && NASR_PSTAMP
+    {   // every workgroup's wave 0: the slowest chain sets the step; a phase that waits for others (poll) is shortest there
+      const char* nm[7] = {"loop-top", "poll", "payload", "mfma", "barrier", "cell", "store-ack"};
+      for (int ph = 0; ph < 7; ++ph) {
+        std::vector<double> v;
+        for (int i = 0; i < 256; ++i) v.push_back(hc.stamps[i][ph] / (double)T);
+        std::sort(v.begin(), v.end());
+        printf("   fwd %-9s over 256 CUs: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f\n", nm[ph], v[0], v[25], v[128], v[230], v[255]);
+      }
+      int lo = 0;
+      for (int i = 1; i < 256; ++i) if (hc.stamps[i][1] < hc.stamps[lo][1]) lo = i;
+      printf("   fwd CU with the shortest poll (xcc %d member %d):", lo / 32, lo % 32);
+      for (int ph = 0; ph < 7; ++ph) printf(" %s %.0f", nm[ph], hc.stamps[lo][ph] / (double)T);
+      printf("\n");
+    }
+#endif
     if (hc.error) return 1;
     // ---- backward, per-step (on the per-step forward's buffers)
     CK(hipMemsetAsync(par, 0, ps * 4, st)); CK(hipMemsetAsync(dcs, 0, hs * 4, st));
@@ -148,6 +165,22 @@ int main(int argc, char** argv) {
              hc.pad[0] / (double)T, hc.pad[1] / (double)T, hc.pad[2] / (double)T, hc.pad[3] / (double)T, hc.pad[4] / (double)T, hc.pad[5] / (double)T,
              hc.pad[6] / (double)T);
     }
+#if defined(NASR_PSTAMP) && NASR_PSTAMP
+    {
+      const char* nm[7] = {"tail", "poll", "loads+sum", "cell", "barrier", "mfma+st", "store-ack"};
+      for (int ph = 0; ph < 7; ++ph) {
+        std::vector<double> v;
+        for (int i = 0; i < 256; ++i) v.push_back(hc.stamps[i][ph] / (double)T);
+        std::sort(v.begin(), v.end());
+        printf("   bwd %-9s over 256 CUs: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f\n", nm[ph], v[0], v[25], v[128], v[230], v[255]);
+      }
+      int lo = 0;
+      for (int i = 1; i < 256; ++i) if (hc.stamps[i][1] < hc.stamps[lo][1]) lo = i;
+      printf("   bwd CU with the shortest poll (xcc %d member %d):", lo / 32, lo % 32);
+      for (int ph = 0; ph < 7; ++ph) printf(" %s %.0f", nm[ph], hc.stamps[lo][ph] / (double)T);
+      printf("\n");
+    }
+#endif
     if (hc.error) return 1;
   }
   double ma;
