@@ -1,5 +1,5 @@
-// gemm_tph.hip — the tiled-plane GEMM of gemm_tp.hip on TWO fp16 parts per element and THREE MFMA products instead of
-// three bf16 parts and six products:
+// gemm_tph.hip — the bulk GEMM of the step: fp32 products from operands kept as TWO fp16 parts per element ("tiled
+// planes") and THREE MFMA products:
 //     C[M,N] = A[M,K] * B[N,K]^T (+bias[n])
 //
 // x*s = h1 + h2 with h1 = fp16(x*s), h2 = fp16(x*s - h1): the two 11-bit significands and the sign of h2 hold x*s to
@@ -13,7 +13,8 @@
 // accuracy class as the six bf16 products (bf16's 8-bit exponent needs no scale, its 8-bit significand three parts), at
 // half the matrix-core work and two thirds of the operand bytes.
 //
-// Layout: TPH[rb = row/32][kb = k/16][part 0..1][1 KiB tile], tiles swizzled as in gemm_tp.hip (tph_slot).  Kernel: 256
+// Layout: TPH[rb = row/32][kb = k/16][part 0..1][1 KiB tile = 32 rows x 16 k], tiles XOR-swizzled (tph_slot) so that the
+// fragment reads are conflict-free ds_read_b128.  Kernel: 256
 // (or 192) x 256 output tile, TWO k-blocks per barrier (the 3-product chain is half as long: 48 MFMAs per wave and
 // barrier as before), two 64 KiB LDS buffers, 8 LDS-DMA instructions per wave and step.
 #include "kernels.h"
@@ -310,6 +311,14 @@ __global__ __launch_bounds__(256) void tph_split2_kernel(const float* __restrict
   }
 }
 
+int tp_split2_parts(int rows) { return (rows + 63) / 64; }
+
+// 192-row block tiles where 256-row tiles would leave more than a tenth of their rows empty
+int gemm_tp_tile_rows(int M) {
+  const int w256 = (M + 255) / 256 * 256 - M, w192 = (M + 191) / 192 * 192 - M;
+  return (10 * w256 > M && w192 < w256) ? 192 : 256;
+}
+
 size_t tph_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 2 * HTB; }
 
 void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
@@ -438,7 +447,8 @@ hipError_t gemm_tph_prepare() {
   return e;
 }
 
-// same cost model as gemm_tp_pick_split with a k-step of half the duration; slices are even numbers of k-blocks
+// K split by a cost model in units of one k-step of one block: blocks run in rounds of 256 (one per CU), every slice keeps
+// >= 32 k-blocks, and each slab costs a write + a read of M x N floats at ~4 TB/s; slices are even numbers of k-blocks
 int gemm_tph_pick_split(int M, int N, int K, int nbatch) {
   const int tm = gemm_tp_tile_rows(M);
   const int tiles = ((M + tm - 1) / tm) * ((N + 255) / 256) * (nbatch > 1 ? 2 : 1);

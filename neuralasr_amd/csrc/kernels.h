@@ -31,58 +31,11 @@ struct GemmDesc {
 void launch_gemm(const GemmDesc& g, hipStream_t st);
 int gemm_pick_split(int M, int N, int K);
 
-// ---- fp32-accurate NT GEMM on the bf16 matrix cores (gemm_bf16.hip): C[M,N] = A[M,K] * B[N,K]^T (+bias) ----
-struct GemmNTDesc {
-  const float* A;       // [M][lda], K contiguous
-  const float* B;       // [N][ldb], K contiguous
-  float* C;             // [M][ldc]
-  int M, N, K;          // all multiples of 4
-  int lda, ldb, ldc;
-  int a_kshift;         // A read at k + a_kshift, zero outside [0,K)
-  const float* bias;    // per-n or NULL
-  int split_k;
-  float* slabs;         // split_k*M*N floats when split_k > 1
-};
-void launch_gemm_nt(const GemmNTDesc& g, hipStream_t st);
-void launch_transpose(const float* in, float* out, int R, int C, int ld_in, int ld_out, hipStream_t st);
-
-// ---- fp32-accurate GEMM from pre-split, pre-tiled bf16 operands (gemm_tp.hip): C[M,N] = A[M,K] * B[N,K]^T (+bias) ----
-// A "tiled planes" (TP) operand holds the three bf16 parts of an fp32 matrix [rows][K] as 1 KiB tiles
-// TP[row/32][k/16][part][32 rows x 16 k]; tp_bytes() sizes it, launch_tp_split() fills it from fp32 (element (row,k) =
-// src[row*ld + k], or src[k*ld + row] when `transposed`).
-size_t tp_bytes(int rows, int K);
-void launch_tp_split(const float* src, unsigned char* tp, int rows, int K, int ld, bool transposed, hipStream_t st);
-// both forms in one pass over src [rows][K]: tpN = planes of src (or NULL), tpT = planes of its transpose ([K rows][rows]);
-// colpart (or NULL): tp_split2_parts(rows) x K partial column sums of src, finished by launch_colsum_parts
-int tp_split2_parts(int rows);
-void launch_tp_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, float* colpart,
-                      hipStream_t st);
-struct GemmTPDesc {
-  const unsigned char* A;   // TP of [>= M rows][K_A], starting at the first row block used
-  const unsigned char* B;   // TP of [>= N rows][K_B]
-  float* C;
-  int M, N, K;              // M, N multiples of 4 (row blocks past M / N read as zero), K = contraction length
-  int nkbA, nkbB;           // k-blocks per row block in A / B: ceil(K_A/16), ceil(K_B/16)
-  int ldc;
-  int a_kshift;             // multiple of 16: A is read at k + a_kshift, zero outside [0, K_A)
-  const float* bias;        // per-n, only with split_k == 1
-  int split_k;              // > 1: partial slabs + reduction; needs ldc == N and no bias
-  float* slabs;             // split_k * M * N floats
-  int tile_rows;            // 0: gemm_tp_tile_rows(M); 192 / 256 forces the block tile (tools/gemmbench.hip)
-  // nbatch == 2: a second product of the same shape in the same launch (the two directions' recurrent weight gradients):
-  // its operands start a_bstride / b_bstride BYTES after A / B, its result c_bstride floats after C, its A shift is
-  // a_kshift1.  With split_k > 1: c_bstride must be M * N (one reduction covers both) and slabs hold 2 * split_k * M * N.
-  int nbatch;
-  size_t a_bstride, b_bstride;
-  int64_t c_bstride;
-  int a_kshift1;
-};
-hipError_t gemm_tp_prepare();    // once per process: raise the kernel's dynamic-LDS limit
-int gemm_tp_tile_rows(int M);
-int gemm_tp_pick_split(int M, int N, int K, int nbatch = 1);
-void launch_gemm_tp(const GemmTPDesc& g, hipStream_t st);
-
-// ---- the same GEMM on two fp16 planes per element and three MFMA products (gemm_tph.hip) ----
+// ---- fp32-accurate GEMM from pre-split, pre-tiled fp16 operands (gemm_tph.hip): C[M,N] = A[M,K] * B[N,K]^T (+bias) ----
+// A "tiled planes" operand holds the two fp16 parts of a scaled fp32 matrix [rows][K] as 1 KiB tiles
+// TPH[row/32][k/16][part][32 rows x 16 k]; tph_bytes() sizes it, launch_tph_split2() fills it from fp32.
+int tp_split2_parts(int rows);           // 64-row partial column sums the split pass can emit
+int gemm_tp_tile_rows(int M);            // 256, or 192 where 256-row tiles would leave > 10 % of their rows empty
 // Every operand row carries a power-of-two scale (constant along the contraction) that brings its largest magnitude into
 // [2^14, 2^15); the epilogue multiplies by the inverse scales of the output's row and column.
 size_t tph_bytes(int rows, int K);
@@ -97,23 +50,27 @@ size_t tph_scale_batch_ws_floats(const TphScaleJob* jobs, int n);
 void launch_tph_scales_batch(const TphScaleJob* jobs, int n, float* ws, hipStream_t st);
 void launch_fill(float* p, float v, int n, hipStream_t st);
 // one pass over src [rows][K]: tpN = planes of src (scale per src row: row_scale[] or the constant rs), tpT = planes of its
-// transpose (scale per src column: col_scale[] or cs); either may be NULL; colpart as in launch_tp_split2
+// transpose (scale per src column: col_scale[] or cs); either may be NULL; colpart (or NULL): tp_split2_parts(rows) x K
+// partial column sums of src, finished by launch_colsum_parts
 void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
                        const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st);
 struct GemmTPHDesc {
-  const unsigned char* A;   // TPH of [>= M rows][K_A]
+  const unsigned char* A;   // TPH of [>= M rows][K_A], starting at the first row block used
   const unsigned char* B;   // TPH of [>= N rows][K_B]
   float* C;
-  int M, N, K;
-  int nkbA, nkbB;
+  int M, N, K;              // M, N multiples of 4 (row blocks past M / N read as zero), K = contraction length
+  int nkbA, nkbB;           // k-blocks per row block in A / B: ceil(K_A/16), ceil(K_B/16)
   int ldc;
-  int a_kshift;
-  const float* bias;
+  int a_kshift;             // multiple of 16: A is read at k + a_kshift, zero outside [0, K_A)
+  const float* bias;        // per-n, only with split_k == 1
   const float* a_inv;       // [M] inverse scales of A's rows
   const float* b_inv;       // [N] inverse scales of B's rows
-  int split_k;
-  float* slabs;
-  int tile_rows;
+  int split_k;              // > 1: partial slabs + reduction; needs ldc == N and no bias
+  float* slabs;             // split_k * M * N floats
+  int tile_rows;            // 0: gemm_tp_tile_rows(M); 192 / 256 forces the block tile (tools/gemmbench.hip)
+  // nbatch == 2: a second product of the same shape in the same launch (the two directions' recurrent weight gradients):
+  // its operands start a_bstride / b_bstride BYTES after A / B, its result c_bstride floats after C, its A shift is
+  // a_kshift1.  With split_k > 1: c_bstride must be M * N (one reduction covers both) and slabs hold 2 * split_k * M * N.
   int nbatch;
   size_t a_bstride, b_bstride;
   int64_t c_bstride, ainv_bstride, binv_bstride;

@@ -59,7 +59,6 @@ struct TensorInfo {
 
 enum Phase { PH_PACK = 0, PH_XPROJ, PH_RECF, PH_PROJCTC, PH_PROJB, PH_RECB, PH_WGRAD, PH_ADAM, PH_COUNT };
 
-constexpr int PIPE_MAX_CHUNKS = 16;
 constexpr int GRAD_HEAD = 32;   // floats in front of the gradients (h->G = h->Gbase + GRAD_HEAD); [0] = fault word of the step
 constexpr int MAX_BUCKETS = 16;
 
@@ -103,19 +102,10 @@ struct nasr_ctx {
   int device = 0;
   hipStream_t st = nullptr;
   bool own_stream = false;
-  // Unidirectional stacks (LstmCTCNet): layer l works on time chunk c while layer l+1 works on chunk c-1, each
-  // layer on its own stream (a uni-directional step launch fills only half the CUs).
-  bool pipe = false;
-  int pipe_chunks = 1;                 // chunks of the resident batch (1 = not pipelined)
-  std::vector<hipStream_t> lst;        // per-layer streams, lst[0] == st
-  hipEvent_t ev_fork = nullptr;
-  std::vector<hipEvent_t> ev_done, ev_dx;   // [layer * PIPE_MAX_CHUNKS + chunk]
-  bool gemm_bf16 = true;               // bulk GEMMs on the bf16 matrix cores (fp32-accurate 3-way split), NASR_GEMM=f32 disables
-  // NASR_GEMM=tp (default): the same arithmetic from operands split ONCE into tiled bf16 planes (gemm_tp.hip);
-  // NASR_GEMM=bf16 keeps the split-while-staging kernel (gemm_bf16.hip), NASR_GEMM=f32 the f32-MFMA kernel (gemm.hip).
-  bool gemm_tp = true;
-  unsigned char* WfTP = nullptr;       // per layer TP of Wx^T [D*N4][Ip]: B operand of the input GEMM
-  unsigned char* WbTP = nullptr;       // per layer (l >= 1) TP of Wx [Ip][D*N4]: B operand of the input-gradient GEMM
+  // Bulk GEMMs (input projections, input / weight gradients, dense stages): fp32 products from two fp16 planes per
+  // operand and three MFMA products (gemm_tph.hip); the planes are tiled copies made once per operand.
+  unsigned char* WfTP = nullptr;       // per layer planes of Wx^T [D*N4][Ip]: B operand of the input GEMM
+  unsigned char* WbTP = nullptr;       // per layer (l >= 1) planes of Wx [Ip][D*N4]: B operand of the input-gradient GEMM
   std::vector<size_t> off_wftp, off_wbtp;
   // Persistent recurrence (lstm_persist.hip): one launch per layer pass instead of T step launches.  Needs the full
   // 8 XCD x 32 CU chip and Hp <= 512; NASR_PERSIST=0 keeps the per-step kernels.
@@ -170,11 +160,8 @@ struct nasr_ctx {
   uint32_t drop_seed = 4567u, drop_counter = 0;   // random_seed of networks/deepspeech.py:26
 
   float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr, *Uf = nullptr, *Ub = nullptr;
-  bool split2 = true;                        // NASR_SPLIT2=0: separate passes for the two plane sets of dG (A/B knob)
-  // Plane format of the tiled-plane GEMMs: three bf16 planes + six MFMA products (gemm_tp.hip; NASR_GEMM=tp3), or two
-  // fp16 planes + three products with a power-of-two scale per operand row (gemm_tph.hip; the default).  Scale vectors
-  // (device floats, scale and 1/scale): measured per step for everything whose range is not known in advance.
-  bool tph = false;
+  // Every operand row of a plane GEMM carries a power-of-two scale (device floats, scale and 1/scale), measured per step
+  // for everything whose range is not known in advance.
   struct SV {
     DevBuf s, inv;
     bool ensure(size_t n) { bool g = false; return s.ensure(n * 4, &g) && inv.ensure(n * 4, &g); }
@@ -200,8 +187,6 @@ struct nasr_ctx {
   // weight_grads(l), so that a collective released by it co-runs with the GEMM phase of layer l-1, not with the launch
   // that wants every CU's memory queue to itself (nasr_set_bucket_defer; NASR_BUCKET_DEFER=0 at create).
   bool bucket_defer = true;
-  float* WxT = nullptr;                // per layer [D*N4][Ip]: transposed input weights (K-contiguous B operand)
-  std::vector<int64_t> off_wxt;
   int64_t adam_step = 0;
   float lr;
 
@@ -219,11 +204,11 @@ struct nasr_ctx {
   int32_t *seq_p = nullptr, *lablen_p = nullptr, *labels_p = nullptr, *cstart_p = nullptr, *cpos_p = nullptr,
           *rowmap_p = nullptr;
 
-  DevBuf XTP, X0TTP, OTTP0, OTTP1, GTP, GTTP;   // tiled-plane copies of activations / dG (gemm_tp)
-  DevBuf X0T, outT0, outT1, dGT, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, slabs, csws, amax, ids, lens,
+  DevBuf XTP, X0TTP, OTTP0, OTTP1, GTP, GTTP;   // tiled-plane copies of activations / dG
+  DevBuf seqbuf, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, slabs, csws, amax, ids, lens,
       stage;
   std::vector<DevBuf> gates, outb, cbuf;
-  std::vector<DevBuf> doutL, hstateL, partialL, dcstateL, dgL;   // one each, or one per layer when pipelined
+  DevBuf dout, hstate, partial, dcstate, dgbuf;   // shared by the layers (a layer's backward pass is over before the next starts)
 
   // graphs
   bool graph_mode = true;
@@ -258,41 +243,24 @@ namespace {
 
 // A persistent launch that gave up (bounded spin, unexpected placement) leaves its outputs undefined: surface it at
 // the next host sync and use the per-step kernels from then on.
-// ---- tiled planes in either format ----------------------------------------------------------------------------
-inline size_t pl_rb_bytes(const nasr_ctx* h, int nkb) { return (size_t)nkb * (h->tph ? 2 : 3) * 1024; }   // one row block
-inline int pl_pick_split(const nasr_ctx* h, int M, int N, int K, int nbatch = 1) {
-  return h->tph ? gemm_tph_pick_split(M, N, K, nbatch) : gemm_tp_pick_split(M, N, K, nbatch);
-}
-// scales of src [rows][K]: per row into `row`, per column into `col` (either may be NULL); fp16 planes only
+// ---- tiled fp16 planes (gemm_tph.hip) ---------------------------------------------------------------------------
+inline size_t pl_rb_bytes(int nkb) { return (size_t)nkb * 2 * 1024; }   // one 32-row block: nkb k-blocks x 2 parts x 1 KiB
+// scales of src [rows][K]: per row into `row`, per column into `col` (either may be NULL)
 void pl_scales(nasr_ctx* h, const float* src, int rows, int K, int ld, nasr_ctx::SV* row, nasr_ctx::SV* col, hipStream_t st) {
-  if (!h->tph) return;
   launch_tph_scales(src, rows, K, ld, row ? row->sp() : nullptr, row ? row->ip() : nullptr, col ? col->sp() : nullptr,
                     col ? col->ip() : nullptr, h->scws.as<float>(), st);
 }
 // planes of src [rows][K] (tpN, scaled per row by rs[]) and / or of its transpose (tpT, scaled per src column by cs[]);
-// colpart: partial column sums for launch_colsum_parts (bf16 planes: needs split2)
-void pl_split(nasr_ctx* h, const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
-              const float* rs, const float* cs, float* colpart, hipStream_t st) {
-  if (h->tph) {
-    launch_tph_split2(src, tpN, tpT, rows, K, ld, rs, 1.f, cs, 1.f, colpart, st);
-  } else if ((tpN && tpT) || colpart) {
-    launch_tp_split2(src, tpN, tpT, rows, K, ld, colpart, st);
-  } else if (tpN) {
-    launch_tp_split(src, tpN, rows, K, ld, false, st);
-  } else {
-    launch_tp_split(src, tpT, K, rows, ld, true, st);
-  }
+// colpart: 64-row partial column sums for launch_colsum_parts
+void pl_split(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld, const float* rs,
+              const float* cs, float* colpart, hipStream_t st) {
+  launch_tph_split2(src, tpN, tpT, rows, K, ld, rs, 1.f, cs, 1.f, colpart, st);
 }
-// a_inv / b_inv: inverse scales of A's / B's rows (fp16 planes); the strides apply to batch 1 of a two-batch launch
-void pl_gemm(nasr_ctx* h, const GemmTPDesc& g, const float* a_inv, const float* b_inv, hipStream_t st,
-             int64_t ainv_bstride = 0, int64_t binv_bstride = 0) {
-  if (!h->tph) { launch_gemm_tp(g, st); return; }
-  GemmTPHDesc t{};
-  t.A = g.A; t.B = g.B; t.C = g.C; t.M = g.M; t.N = g.N; t.K = g.K; t.nkbA = g.nkbA; t.nkbB = g.nkbB; t.ldc = g.ldc;
-  t.a_kshift = g.a_kshift; t.bias = g.bias; t.a_inv = a_inv; t.b_inv = b_inv; t.split_k = g.split_k; t.slabs = g.slabs;
-  t.tile_rows = g.tile_rows; t.nbatch = g.nbatch; t.a_bstride = g.a_bstride; t.b_bstride = g.b_bstride;
-  t.c_bstride = g.c_bstride; t.ainv_bstride = ainv_bstride; t.binv_bstride = binv_bstride; t.a_kshift1 = g.a_kshift1;
-  launch_gemm_tph(t, st);
+// a_inv / b_inv: inverse scales of A's / B's rows; the strides apply to batch 1 of a two-batch launch
+void pl_gemm(GemmTPHDesc g, const float* a_inv, const float* b_inv, hipStream_t st, int64_t ainv_bstride = 0,
+             int64_t binv_bstride = 0) {
+  g.a_inv = a_inv; g.b_inv = b_inv; g.ainv_bstride = ainv_bstride; g.binv_bstride = binv_bstride;
+  launch_gemm_tph(g, st);
 }
 // scale vectors of an activation tensor: the features, a dense stage's output (index i), or an LSTM layer's output
 struct ActScale { const float *rs, *rinv, *cs, *cinv; };
@@ -590,8 +558,8 @@ int repack(nasr_ctx* h) {
         launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
       }
   }
-  if (h->gemm_tp) {
-    if (h->tph) {   // scales of every weight matrix in two launches
+  {
+    {   // scales of every weight matrix in two launches
       std::vector<TphScaleJob> jobs;
       for (int l = 0; l < h->L; ++l) {
         const bool back = l > 0 || h->npre > 0;
@@ -609,19 +577,16 @@ int repack(nasr_ctx* h) {
       // forward operand = planes of Wx^T, input-gradient operand = planes of Wx: one pass where both are needed
       const bool back = l > 0 || h->npre > 0;
       const float* W = h->P + h->off_wx[l];
-      pl_split(h, W, back ? h->WbTP + h->off_wbtp[l] : nullptr, h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
-               h->D * h->N4, h->tph && back ? h->sc_wr[l].sp() : nullptr, h->tph ? h->sc_wc[l].sp() : nullptr, nullptr, h->st);
+      pl_split(W, back ? h->WbTP + h->off_wbtp[l] : nullptr, h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
+               h->D * h->N4, back ? h->sc_wr[l].sp() : nullptr, h->sc_wc[l].sp(), nullptr, h->st);
     }
     for (int i = 0; i < h->ndense; ++i) {
       const bool back = i > 0 || h->npre == 0;   // the first pre stage reads the features: no gradient wrt its input
       const float* W = h->P + h->off_dw[i];
-      pl_split(h, W, back ? h->DbTP + h->off_dbtp[i] : nullptr, h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i], h->dWp[i],
-               h->tph && back ? h->sc_dr[i].sp() : nullptr, h->tph ? h->sc_dc[i].sp() : nullptr, nullptr, h->st);
+      pl_split(W, back ? h->DbTP + h->off_dbtp[i] : nullptr, h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i], h->dWp[i],
+               back ? h->sc_dr[i].sp() : nullptr, h->sc_dc[i].sp(), nullptr, h->st);
     }
-  } else if (h->gemm_bf16)
-    for (int l = 0; l < h->L; ++l)
-      launch_transpose(h->P + h->off_wx[l], h->WxT + h->off_wxt[l], h->Ip[l], h->D * h->N4, h->D * h->N4, h->Ip[l],
-                       h->st);
+  }
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
 }
@@ -653,25 +618,24 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   bool grew = false;
   bool ok = true;
   ok &= h->X0.ensure(R * h->Fp * 4, &grew);
-  for (size_t i = 0; i < h->doutL.size(); ++i) {
-    ok &= h->doutL[i].ensure(R * D * Hp * 4, &grew);
-    ok &= h->hstateL[i].ensure((size_t)2 * D * Bp * Hp * 4, &grew);
-    ok &= h->partialL[i].ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
-    ok &= h->dcstateL[i].ensure((size_t)2 * D * Bp * Hp * 4, &grew);
-    ok &= h->dgL[i].ensure(R * D * N4 * 4, &grew);
-  }
-  if (h->gemm_tp) {
+  ok &= h->seqbuf.ensure((size_t)Bp * 4, &grew);
+  ok &= h->dout.ensure(R * D * Hp * 4, &grew);
+  ok &= h->hstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
+  ok &= h->partial.ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
+  ok &= h->dcstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
+  ok &= h->dgbuf.ensure(R * D * N4 * 4, &grew);
+  {
     int ipmax = h->Fp, wmax = D * N4;
     for (int l = 0; l < h->L; ++l) ipmax = std::max(ipmax, h->Ip[l]);
     for (int i = 0; i < h->ndense; ++i) { ipmax = std::max(ipmax, h->dIp[i]); wmax = std::max(wmax, h->dWp[i]); }
-    ok &= h->XTP.ensure(tp_bytes((int)R, ipmax), &grew);
-    ok &= h->X0TTP.ensure(tp_bytes(h->Ip[0], (int)R), &grew);
-    ok &= h->OTTP0.ensure(tp_bytes(D * Hp, (int)R), &grew);
-    ok &= h->OTTP1.ensure(tp_bytes(D * Hp, (int)R), &grew);
-    ok &= h->GTP.ensure(tp_bytes((int)R, wmax), &grew);
-    ok &= h->GTTP.ensure(tp_bytes(wmax, (int)R), &grew);
-    if (h->ndense) ok &= h->DTP.ensure(tp_bytes(ipmax, (int)R), &grew);
-    if (h->tph) {
+    ok &= h->XTP.ensure(tph_bytes((int)R, ipmax), &grew);
+    ok &= h->X0TTP.ensure(tph_bytes(h->Ip[0], (int)R), &grew);
+    ok &= h->OTTP0.ensure(tph_bytes(D * Hp, (int)R), &grew);
+    ok &= h->OTTP1.ensure(tph_bytes(D * Hp, (int)R), &grew);
+    ok &= h->GTP.ensure(tph_bytes((int)R, wmax), &grew);
+    ok &= h->GTTP.ensure(tph_bytes(wmax, (int)R), &grew);
+    if (h->ndense) ok &= h->DTP.ensure(tph_bytes(ipmax, (int)R), &grew);
+    {
       const size_t n15 = std::max<size_t>(R, (size_t)std::max(ipmax, wmax));
       if (n15 > h->sc15_n) {
         ok &= h->sc15.ensure(n15);
@@ -687,11 +651,6 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
       bool g2 = false;
       ok &= h->scws.ensure(tph_scale_ws_floats((int)R, std::max(ipmax, wmax)) * 4, &g2);
     }
-  } else if (h->gemm_bf16) {
-    ok &= h->X0T.ensure(R * h->Fp * 4, &grew);
-    ok &= h->outT0.ensure(R * D * Hp * 4, &grew);
-    ok &= h->outT1.ensure(R * D * Hp * 4, &grew);
-    ok &= h->dGT.ensure(R * D * N4 * 4, &grew);
   }
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
@@ -705,8 +664,8 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->loss.ensure(16, &grew);
   int csw = std::max(D * N4, h->Cp);
   for (int i = 0; i < h->ndense; ++i) csw = std::max(csw, h->dWp[i]);
-  // column-sum partials: 32 rows of launch_colsum, or the 64-row partials of the fused split pass (tp_split2_parts)
-  ok &= h->csws.ensure((size_t)std::max(32, h->gemm_tp ? tp_split2_parts((int)R) : 0) * csw * 4, &grew);
+  // column-sum partials: 32 rows of launch_colsum, or the 64-row partials of the split pass (tp_split2_parts)
+  ok &= h->csws.ensure((size_t)std::max(32, tp_split2_parts((int)R)) * csw * 4, &grew);
   ok &= h->amax.ensure((size_t)Tp * Bp * 4, &grew);
   ok &= h->ids.ensure((size_t)B * Tp * 4, &grew);
   ok &= h->lens.ensure((size_t)Bp * 4, &grew);
@@ -721,8 +680,6 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   }
   if (!ok) return h->fail(NASR_ERR_HIP, "hipMalloc failed while sizing batch buffers");
   if (grew || Bp != h->Bp) drop_graphs(h);
-  // pipeline the layers of a unidirectional stack over time chunks of >= 32 frames
-  h->pipe_chunks = (h->pipe && !h->persist) ? std::max(1, std::min(PIPE_MAX_CHUNKS, std::min(10, T / 32))) : 1;
   h->B = B; h->Bp = Bp; h->T = T; h->Lmax = Lmax; h->Tp = Tp; h->KS = KSa;
   return NASR_OK;
 }
@@ -900,7 +857,9 @@ int slot_commit(nasr_ctx* h, BatchSlot* s) {
   }
   HIPCHK(h, hipStreamWaitEvent(h->st, s->ev_copy, 0));
   int32_t* md = s->meta_d();
-  h->seq_p = md + s->o_seq; h->lablen_p = md + s->o_lablen; h->labels_p = md + s->o_labels;
+  // seq_len lives at a FIXED address: the hipGraphs of the per-step recurrence captured it
+  HIPCHK(h, hipMemcpyAsync(h->seqbuf.p, md + s->o_seq, (size_t)Bp * 4, hipMemcpyDeviceToDevice, h->st));
+  h->seq_p = h->seqbuf.as<int32_t>(); h->lablen_p = md + s->o_lablen; h->labels_p = md + s->o_labels;
   h->cstart_p = md + s->o_cstart; h->cpos_p = md + s->o_cpos; h->rowmap_p = md + s->o_rowmap;
   h->ev_used = 0;
   h->spans.clear();
@@ -920,13 +879,10 @@ int slot_commit(nasr_ctx* h, BatchSlot* s) {
                             h->X0.as<float>(), B, Bp, T, s->ctx, s->ncep, h->Fp, h->st);
     else
       launch_pack_feats(s->dfeats.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
-    if (h->gemm_tp) {
-      pl_scales(h, h->X0.as<float>(), T * Bp, h->Fp, h->Fp, &h->sc_x0r, &h->sc_x0c, h->st);
-      if (s->has_labels && h->npre == 0)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
-        pl_split(h, h->X0.as<float>(), nullptr, h->X0TTP.as<unsigned char>(), T * Bp, h->Fp, h->Fp, nullptr,
-                 h->sc_x0c.sp(), nullptr, h->st);
-    } else if (h->gemm_bf16 && s->has_labels)   // K-contiguous copy of the layer-0 input for dWx = X^T dG
-      launch_transpose(h->X0.as<float>(), h->X0T.as<float>(), T * Bp, h->Fp, h->Fp, T * Bp, h->st);
+    pl_scales(h, h->X0.as<float>(), T * Bp, h->Fp, h->Fp, &h->sc_x0r, &h->sc_x0c, h->st);
+    if (s->has_labels && h->npre == 0)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
+      pl_split(h->X0.as<float>(), nullptr, h->X0TTP.as<unsigned char>(), T * Bp, h->Fp, h->Fp, nullptr, h->sc_x0c.sp(),
+               nullptr, h->st);
     HIPCHK(h, hipGetLastError());
   }
   h->resident = true;
@@ -971,11 +927,8 @@ int stage(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_t
   return NASR_OK;
 }
 
-// per-layer state: one shared set, or one set per layer when the layers are pipelined
-inline size_t lidx(const nasr_ctx* h, int l) { return h->doutL.size() > 1 ? (size_t)l : 0; }
-inline float* dout_of(nasr_ctx* h, int l) { return h->doutL[lidx(h, l)].as<float>(); }
-inline float* dg_of(nasr_ctx* h, int l) { return h->dgL[lidx(h, l)].as<float>(); }
-inline hipStream_t stream_of(nasr_ctx* h, int l) { return (h->pipe_chunks > 1 && l > 0) ? h->lst[l] : h->st; }
+inline float* dout_of(nasr_ctx* h, int) { return h->dout.as<float>(); }
+inline float* dg_of(nasr_ctx* h, int) { return h->dgbuf.as<float>(); }
 
 // ---- the per-timestep loops over steps [s0, s1), optionally replayed from a hipGraph -----------
 int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
@@ -997,9 +950,9 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
   const size_t sU = (size_t)l * h->D * h->Hp * h->N4;
   const size_t hs = (size_t)h->D * h->Bp * h->Hp;   // one h-state image
   const size_t ps = (size_t)h->D * lstm_bwd_partials(h->Hp) * h->Bp * h->Hp;   // one partial-sum image
-  float* hst = h->hstateL[lidx(h, l)].as<float>();
-  float* par = h->partialL[lidx(h, l)].as<float>();
-  float* dcs = h->dcstateL[lidx(h, l)].as<float>();
+  float* hst = h->hstate.as<float>();
+  float* par = h->partial.as<float>();
+  float* dcs = h->dcstate.as<float>();
   auto body = [&]() {
     if (!bwd) {
       if (s0 == 0) (void)hipMemsetAsync(hst, 0, hs * 4, st);
@@ -1055,71 +1008,36 @@ inline const float* lstm_input(nasr_ctx* h, int l) {
   return h->npre ? h->Ybuf[h->npre - 1].as<float>() : h->X0.as<float>();
 }
 
-// gates_l[r0 .. r0+nr) = X_l[r0 ..] * Wx_l + bias_l   (rows are time-major, so a time chunk is a row range)
-void gemm_xproj(nasr_ctx* h, int l, int r0, int nr, hipStream_t st) {
+// gates_l = X_l * Wx_l + bias_l over all R rows
+void gemm_xproj(nasr_ctx* h, int l, int R, hipStream_t st) {
   const int D = h->D, N4 = h->N4, Ip = h->Ip[l];
-  const float* Xl = lstm_input(h, l) + (size_t)r0 * Ip;
-  float* C = h->gates[l].as<float>() + (size_t)r0 * D * N4;
-  if (h->gemm_tp) {
-    const ActScale as = lstm_in_scale(h, l);
-    pl_split(h, Xl, h->XTP.as<unsigned char>(), nullptr, nr, Ip, Ip, h->tph ? as.rs + r0 : nullptr, nullptr, nullptr, st);
-    GemmTPDesc g{};
-    g.A = h->XTP.as<unsigned char>(); g.B = h->WfTP + h->off_wftp[l]; g.C = C;
-    g.M = nr; g.N = D * N4; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * N4;
-    g.bias = h->P + h->off_bias[l]; g.split_k = 1;
-    pl_gemm(h, g, h->tph ? as.rinv + r0 : nullptr, h->sc_wc[l].ip(), st);
-  } else if (h->gemm_bf16) {
-    GemmNTDesc g{};
-    g.A = Xl; g.B = h->WxT + h->off_wxt[l]; g.C = C;
-    g.M = nr; g.N = D * N4; g.K = Ip; g.lda = Ip; g.ldb = Ip; g.ldc = D * N4;
-    g.bias = h->P + h->off_bias[l]; g.split_k = 1;
-    launch_gemm_nt(g, st);
-  } else {
-    GemmDesc g{};
-    g.A = Xl; g.B = h->P + h->off_wx[l]; g.C = C;
-    g.M = nr; g.N = D * N4; g.K = Ip; g.lda = Ip; g.ldb = D * N4; g.ldc = D * N4;
-    g.a_rows = nr; g.bias = h->P + h->off_bias[l]; g.split_k = 1;
-    launch_gemm(g, st);
-  }
+  const ActScale as = lstm_in_scale(h, l);
+  pl_split(lstm_input(h, l), h->XTP.as<unsigned char>(), nullptr, R, Ip, Ip, as.rs, nullptr, nullptr, st);
+  GemmTPHDesc g{};
+  g.A = h->XTP.as<unsigned char>(); g.B = h->WfTP + h->off_wftp[l]; g.C = h->gates[l].as<float>();
+  g.M = R; g.N = D * N4; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * N4;
+  g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+  pl_gemm(g, as.rinv, h->sc_wc[l].ip(), st);
 }
 
-// dOut_{l-1}[r0 ..) = dG_l[r0 ..) * Wx_l^T : the gradient wrt layer l's input = the layer below's output
-// with_transposed: the call covers all R rows and weight_grads(l) follows - dG is split once into both plane sets
-void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st, bool with_transposed = false) {
-  const int D = h->D, N4 = h->N4, Hp = h->Hp;
-  const float* A = dg_of(h, l) + (size_t)r0 * D * N4;
-  float* C = l > 0 ? dout_of(h, l - 1) + (size_t)r0 * D * Hp : h->dYbuf[h->npre - 1].as<float>() + (size_t)r0 * h->Ip[0];
-  if (h->gemm_tp) {
-    // fp16 planes: frame-row scales for this product, gate-column scales for the weight gradients (the whole dG when
-    // weight_grads follows, else this row range only - the pipelined path is bf16-only, see nasr_create)
-    if (with_transposed && (h->split2 || h->tph)) {
-      pl_scales(h, A, nr, D * N4, D * N4, &h->sc_gr, &h->sc_gc, st);
-      pl_split(h, A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), nr, D * N4, D * N4, h->sc_gr.sp(),
-               h->sc_gc.sp(), h->csws.as<float>(), st);
-      h->gttp_layer = l;   // weight_grads(l): transposed planes and column-sum partials of dG are there
-    } else {
-      pl_scales(h, A, nr, D * N4, D * N4, &h->sc_gr, nullptr, st);
-      pl_split(h, A, h->GTP.as<unsigned char>(), nullptr, nr, D * N4, D * N4, h->sc_gr.sp(), nullptr, nullptr, st);
-    }
-    GemmTPDesc g{};
-    g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
-    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = h->Ip[l];
-    g.split_k = pl_pick_split(h, g.M, g.N, g.K);
-    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-    if (g.split_k > 1 && !g.slabs) g.split_k = 1;
-    pl_gemm(h, g, h->sc_gr.ip(), h->tph ? h->sc_wr[l].ip() : nullptr, st);
-  } else if (h->gemm_bf16) {
-    GemmNTDesc g{};
-    g.A = A; g.B = h->P + h->off_wx[l]; g.C = C;
-    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp; g.split_k = 1;
-    launch_gemm_nt(g, st);
-  } else {
-    GemmDesc g{};
-    g.A = A; g.B = h->P + h->off_wx[l]; g.C = C;
-    g.M = nr; g.N = h->Ip[l]; g.K = D * N4; g.lda = D * N4; g.ldb = D * N4; g.ldc = D * Hp;
-    g.b_col = true; g.a_rows = nr; g.split_k = 1;
-    launch_gemm(g, st);
-  }
+// dOut_{l-1} = dG_l * Wx_l^T : the gradient wrt layer l's input = the layer below's output.  weight_grads(l) follows:
+// dG is split ONCE into both plane sets (frame-row scales for this product, gate-column scales for the weight gradients)
+// and its 64-row partial column sums (the bias gradient).
+void gemm_dx(nasr_ctx* h, int l, int R, hipStream_t st) {
+  const int D = h->D, N4 = h->N4;
+  const float* A = dg_of(h, l);
+  float* C = l > 0 ? dout_of(h, l - 1) : h->dYbuf[h->npre - 1].as<float>();
+  pl_scales(h, A, R, D * N4, D * N4, &h->sc_gr, &h->sc_gc, st);
+  pl_split(A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), R, D * N4, D * N4, h->sc_gr.sp(), h->sc_gc.sp(),
+           h->csws.as<float>(), st);
+  h->gttp_layer = l;   // weight_grads(l): transposed planes and column-sum partials of dG are there
+  GemmTPHDesc g{};
+  g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
+  g.M = R; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = h->Ip[l];
+  g.split_k = gemm_tph_pick_split(g.M, g.N, g.K);
+  g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+  if (g.split_k > 1 && !g.slabs) g.split_k = 1;
+  pl_gemm(g, h->sc_gr.ip(), h->sc_wr[l].ip(), st);
 }
 
 // ---- dense stages (networks/deepspeech.py:43-68,106-113) -----------------------------------------------------
@@ -1127,12 +1045,12 @@ void gemm_dx(nasr_ctx* h, int l, int r0, int nr, hipStream_t st, bool with_trans
 int dense_forward(nasr_ctx* h, int i, const float* X) {
   const int R = h->T * h->Bp, Ip = h->dIp[i], Wp = h->dWp[i];
   const ActScale as = dense_in_scale(h, i);
-  pl_split(h, X, h->XTP.as<unsigned char>(), nullptr, R, Ip, Ip, h->tph ? as.rs : nullptr, nullptr, nullptr, h->st);
-  GemmTPDesc g{};
+  pl_split(X, h->XTP.as<unsigned char>(), nullptr, R, Ip, Ip, as.rs, nullptr, nullptr, h->st);
+  GemmTPHDesc g{};
   g.A = h->XTP.as<unsigned char>(); g.B = h->DfTP + h->off_dftp[i]; g.C = h->Ybuf[i].as<float>();
   g.M = R; g.N = Wp; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = Wp;
   g.bias = h->P + h->off_db[i]; g.split_k = 1;
-  pl_gemm(h, g, h->tph ? as.rinv : nullptr, h->tph ? h->sc_dc[i].ip() : nullptr, h->st);
+  pl_gemm(g, as.rinv, h->sc_dc[i].ip(), h->st);
   launch_dense_act(h->Ybuf[i].as<float>(), R, h->Bp, h->B, h->dWid[i], Wp, h->cfg.relu_clip, h->cfg.dropout[i],
                    h->drop_seed, h->drop_counter, i, h->st);
   // the stage's output feeds the next GEMM (rows = frames) and, transposed, its weight gradient (rows = features)
@@ -1147,42 +1065,32 @@ int dense_backward(nasr_ctx* h, int i, const float* X, float* dX) {
   const int nkb = (R + 15) / 16;
   float* dZ = h->dYbuf[i].as<float>();
   launch_dense_act_bwd(dZ, h->Ybuf[i].as<float>(), (int64_t)R * Wp, h->cfg.relu_clip, h->cfg.dropout[i], h->st);
-  const bool fused = h->split2 || h->tph;
   const ActScale as = dense_in_scale(h, i);
   pl_scales(h, dZ, R, Wp, Wp, dX ? &h->sc_gr : nullptr, &h->sc_gc, h->st);
-  if (fused)   // both forms of dZ (the first only when an input gradient follows) + column-sum partials in one pass
-    pl_split(h, dZ, dX ? h->GTP.as<unsigned char>() : nullptr, h->GTTP.as<unsigned char>(), R, Wp, Wp, h->sc_gr.sp(),
-             h->sc_gc.sp(), h->csws.as<float>(), h->st);
-  else launch_tp_split(dZ, h->GTTP.as<unsigned char>(), Wp, R, Wp, true, h->st);
-  pl_split(h, X, nullptr, h->DTP.as<unsigned char>(), R, Ip, Ip, nullptr, h->tph ? as.cs : nullptr, nullptr, h->st);
+  // both forms of dZ (the first only when an input gradient follows) + column-sum partials in one pass
+  pl_split(dZ, dX ? h->GTP.as<unsigned char>() : nullptr, h->GTTP.as<unsigned char>(), R, Wp, Wp, h->sc_gr.sp(),
+           h->sc_gc.sp(), h->csws.as<float>(), h->st);
+  pl_split(X, nullptr, h->DTP.as<unsigned char>(), R, Ip, Ip, nullptr, as.cs, nullptr, h->st);
   {  // dW = X^T dZ
-    GemmTPDesc g{};
+    GemmTPHDesc g{};
     g.A = h->DTP.as<unsigned char>(); g.B = h->GTTP.as<unsigned char>(); g.C = h->G + h->off_dw[i];
     g.M = Ip; g.N = Wp; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = Wp;
-    g.split_k = pl_pick_split(h, g.M, g.N, g.K);
+    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-    pl_gemm(h, g, h->tph ? as.cinv : nullptr, h->sc_gc.ip(), h->st);
+    pl_gemm(g, as.cinv, h->sc_gc.ip(), h->st);
   }
-  if (fused) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), Wp, h->G + h->off_db[i], h->st);
-  else launch_colsum(dZ, R, Wp, Wp, h->G + h->off_db[i], h->csws.as<float>(), h->st);
+  launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), Wp, h->G + h->off_db[i], h->st);
   if (dX) {  // dX = dZ W^T
-    if (!fused) launch_tp_split(dZ, h->GTP.as<unsigned char>(), R, Wp, Wp, false, h->st);
-    GemmTPDesc g{};
+    GemmTPHDesc g{};
     g.A = h->GTP.as<unsigned char>(); g.B = h->DbTP + h->off_dbtp[i]; g.C = dX;
     g.M = R; g.N = Ip; g.K = Wp; g.nkbA = (Wp + 15) / 16; g.nkbB = g.nkbA; g.ldc = Ip;
-    g.split_k = pl_pick_split(h, g.M, g.N, g.K);
+    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K);
     g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) g.split_k = 1;
-    pl_gemm(h, g, h->sc_gr.ip(), h->tph ? h->sc_dr[i].ip() : nullptr, h->st);
+    pl_gemm(g, h->sc_gr.ip(), h->sc_dr[i].ip(), h->st);
   }
   HIPCHK(h, hipGetLastError());
-  return NASR_OK;
-}
-
-int pipe_fork(nasr_ctx* h) {
-  HIPCHK(h, hipEventRecord(h->ev_fork, h->st));
-  for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->lst[l], h->ev_fork, 0));
   return NASR_OK;
 }
 
@@ -1191,7 +1099,6 @@ int forward(nasr_ctx* h) {
   const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp;
   const int R = T * Bp;
   h->n_fwd_launch = 0;
-  const int NC = h->pipe_chunks;
   // the fault word of the pass that starts here (a training step or a forward-only call); what an unread earlier word
   // said is gone with it
   HIPCHK(h, hipMemsetAsync(h->Gbase, 0, GRAD_HEAD * 4, h->st));
@@ -1203,40 +1110,16 @@ int forward(nasr_ctx* h) {
     int rc = dense_forward(h, i, i == 0 ? h->X0.as<float>() : h->Ybuf[i - 1].as<float>());
     if (rc) return rc;
   }
-  if (NC <= 1) {
-    for (int l = 0; l < h->L; ++l) {
-      {
-        PhaseScope ps(h, PH_XPROJ);
-        gemm_xproj(h, l, 0, R, h->st);
-        HIPCHK(h, hipGetLastError());
-      }
-      PhaseScope ps(h, PH_RECF);
-      int rc = run_steps(h, l, false, 0, T, h->st);
-      if (rc) return rc;
-      h->n_fwd_launch += h->persist ? 1 : T;
+  for (int l = 0; l < h->L; ++l) {
+    {
+      PhaseScope ps(h, PH_XPROJ);
+      gemm_xproj(h, l, R, h->st);
+      HIPCHK(h, hipGetLastError());
     }
-  } else {
-    // layer l, chunk c needs layer l-1's chunk c and its own chunk c-1 (same stream)
     PhaseScope ps(h, PH_RECF);
-    const int Tc = (T + NC - 1) / NC;
-    int rc = pipe_fork(h);
+    int rc = run_steps(h, l, false, 0, T, h->st);
     if (rc) return rc;
-    for (int c = 0; c < NC; ++c) {
-      const int t0 = c * Tc, t1 = std::min(T, t0 + Tc);
-      if (t0 >= t1) break;
-      for (int l = 0; l < h->L; ++l) {
-        hipStream_t st = stream_of(h, l);
-        if (l > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_done[(l - 1) * PIPE_MAX_CHUNKS + c], 0));
-        gemm_xproj(h, l, t0 * Bp, (t1 - t0) * Bp, st);
-        rc = run_steps(h, l, false, t0, t1, st);
-        if (rc) return rc;
-        HIPCHK(h, hipEventRecord(h->ev_done[l * PIPE_MAX_CHUNKS + c], st));
-      }
-    }
-    const int lastc = (T - 1) / Tc;
-    for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_done[l * PIPE_MAX_CHUNKS + lastc], 0));
-    h->n_fwd_launch = T + (h->L - 1) * Tc;   // length of the critical path in step launches
-    HIPCHK(h, hipGetLastError());
+    h->n_fwd_launch += h->persist ? 1 : T;
   }
   if (h->has_post) {
     PhaseScope ps(h, PH_XPROJ);
@@ -1297,107 +1180,45 @@ int weight_grads(nasr_ctx* h, int l) {
   const int R = T * Bp;
   float* dG = dg_of(h, l);
   hipStream_t ws = h->st;
-  const float* Xl = lstm_input(h, l);
-  if (h->gemm_tp) {
-    // tiled-plane copies with the frame index as contraction index (K = R)
-    unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
-    unsigned char* GT = h->GTTP.as<unsigned char>();
-    const int nkb = (R + 15) / 16;
-    // one pass over dG: its transposed planes + 64-row partial column sums (and, in gemm_dx, its own planes)
-    const bool fused = h->split2 || h->tph;
-    if (h->gttp_layer != l) {
-      pl_scales(h, dG, R, D * N4, D * N4, nullptr, &h->sc_gc, ws);
-      if (fused) pl_split(h, dG, nullptr, GT, R, D * N4, D * N4, nullptr, h->sc_gc.sp(), h->csws.as<float>(), ws);
-      else launch_tp_split(dG, GT, D * N4, R, D * N4, true, ws);
-    }
-    h->gttp_layer = -1;
-    const ActScale ao = act_out(h), ai = lstm_in_scale(h, l);
-    if (l == h->L - 1) pl_split(h, h->outb[l].as<float>(), nullptr, tO[l & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
-    if (l > 0) pl_split(h, h->outb[l - 1].as<float>(), nullptr, tO[(l - 1) & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
-    if (l == 0 && h->npre) pl_split(h, Xl, nullptr, h->X0TTP.as<unsigned char>(), R, h->Ip[0], h->Ip[0], nullptr, ai.cs, nullptr, ws);
-    {  // dWx = X^T dG
-      GemmTPDesc g{};
-      g.A = l == 0 ? h->X0TTP.as<unsigned char>() : tO[(l - 1) & 1];
-      g.B = GT; g.C = h->G + h->off_wx[l];
-      g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
-      g.split_k = pl_pick_split(h, g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      pl_gemm(h, g, ai.cinv, h->sc_gc.ip(), ws);
-    }
-    if (fused) launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
-    else launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
-    {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw); both directions in one launch
-      GemmTPDesc g{};
-      g.A = tO[l & 1]; g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
-      g.M = Hp; g.N = N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
-      g.a_kshift = -Bp;
-      g.nbatch = D;
-      g.a_bstride = (size_t)(Hp / 32) * pl_rb_bytes(h, nkb); g.b_bstride = (size_t)(N4 / 32) * pl_rb_bytes(h, nkb);
-      g.c_bstride = (int64_t)Hp * N4;            // off_u[l*D + 1] - off_u[l*D] (build_layout)
-      g.a_kshift1 = Bp;
-      g.split_k = pl_pick_split(h, g.M, g.N, g.K, D);
-      g.slabs = ensure_slabs(h, g.split_k * D, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      pl_gemm(h, g, ao.cinv, h->sc_gc.ip(), ws, Hp, N4);
-    }
-  } else if (h->gemm_bf16) {
-    // K-contiguous copies of the operands whose contraction index is the row (time) index
-    float* tOut[2] = {h->outT0.as<float>(), h->outT1.as<float>()};
-    launch_transpose(dG, h->dGT.as<float>(), R, D * N4, D * N4, R, ws);
-    if (l == h->L - 1) launch_transpose(h->outb[l].as<float>(), tOut[l & 1], R, D * Hp, D * Hp, R, ws);
-    if (l > 0) launch_transpose(h->outb[l - 1].as<float>(), tOut[(l - 1) & 1], R, D * Hp, D * Hp, R, ws);
-    const float* XT = l == 0 ? h->X0T.as<float>() : tOut[(l - 1) & 1];
-    {  // dWx = X^T dG
-      GemmNTDesc g{};
-      g.A = XT; g.B = h->dGT.as<float>(); g.C = h->G + h->off_wx[l];
-      g.M = h->Ip[l]; g.N = D * N4; g.K = R;
-      g.lda = R; g.ldb = R; g.ldc = D * N4;
-      g.split_k = gemm_pick_split(g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm_nt(g, ws);
-    }
-    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
-    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
-      GemmNTDesc g{};
-      g.A = tOut[l & 1] + (size_t)d * Hp * R;
-      g.B = h->dGT.as<float>() + (size_t)d * N4 * R;
-      g.C = h->G + h->off_u[(size_t)l * D + d];
-      g.M = Hp; g.N = N4; g.K = R;
-      g.lda = R; g.ldb = R; g.ldc = N4;
-      g.a_kshift = d == 0 ? -Bp : Bp;
-      g.split_k = gemm_pick_split(g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm_nt(g, ws);
-    }
-  } else {
-    {  // dWx = X^T dG
-      GemmDesc g{};
-      g.A = Xl; g.B = dG; g.C = h->G + h->off_wx[l];
-      g.M = h->Ip[l]; g.N = D * N4; g.K = R;
-      g.lda = h->Ip[l]; g.ldb = D * N4; g.ldc = D * N4;
-      g.a_col = true; g.a_rows = R;
-      g.split_k = gemm_pick_split(g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm(g, ws);
-    }
-    launch_colsum(dG, R, D * N4, D * N4, h->G + h->off_bias[l], h->csws.as<float>(), ws);
-    for (int d = 0; d < D; ++d) {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw)
-      GemmDesc g{};
-      g.A = h->outb[l].as<float>() + d * Hp;
-      g.B = dG + d * N4;
-      g.C = h->G + h->off_u[(size_t)l * D + d];
-      g.M = Hp; g.N = N4; g.K = R;
-      g.lda = D * Hp; g.ldb = D * N4; g.ldc = N4;
-      g.a_col = true; g.a_shift = d == 0 ? -Bp : Bp; g.a_rows = R;
-      g.split_k = gemm_pick_split(g.M, g.N, g.K);
-      g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
-      if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-      launch_gemm(g, ws);
-    }
+  // tiled-plane copies with the frame index as contraction index (K = R)
+  unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
+  unsigned char* GT = h->GTTP.as<unsigned char>();
+  const int nkb = (R + 15) / 16;
+  // one pass over dG: its transposed planes + 64-row partial column sums (already there when gemm_dx(l) ran)
+  if (h->gttp_layer != l) {
+    pl_scales(h, dG, R, D * N4, D * N4, nullptr, &h->sc_gc, ws);
+    pl_split(dG, nullptr, GT, R, D * N4, D * N4, nullptr, h->sc_gc.sp(), h->csws.as<float>(), ws);
+  }
+  h->gttp_layer = -1;
+  const ActScale ao = act_out(h), ai = lstm_in_scale(h, l);
+  if (l == h->L - 1) pl_split(h->outb[l].as<float>(), nullptr, tO[l & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
+  if (l > 0) pl_split(h->outb[l - 1].as<float>(), nullptr, tO[(l - 1) & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
+  if (l == 0 && h->npre)
+    pl_split(lstm_input(h, l), nullptr, h->X0TTP.as<unsigned char>(), R, h->Ip[0], h->Ip[0], nullptr, ai.cs, nullptr, ws);
+  {  // dWx = X^T dG
+    GemmTPHDesc g{};
+    g.A = l == 0 ? h->X0TTP.as<unsigned char>() : tO[(l - 1) & 1];
+    g.B = GT; g.C = h->G + h->off_wx[l];
+    g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
+    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K);
+    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+    if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+    pl_gemm(g, ai.cinv, h->sc_gc.ip(), ws);
+  }
+  launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
+  {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw); both directions in one launch
+    GemmTPHDesc g{};
+    g.A = tO[l & 1]; g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
+    g.M = Hp; g.N = N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
+    g.a_kshift = -Bp;
+    g.nbatch = D;
+    g.a_bstride = (size_t)(Hp / 32) * pl_rb_bytes(nkb); g.b_bstride = (size_t)(N4 / 32) * pl_rb_bytes(nkb);
+    g.c_bstride = (int64_t)Hp * N4;            // off_u[l*D + 1] - off_u[l*D] (build_layout)
+    g.a_kshift1 = Bp;
+    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K, D);
+    g.slabs = ensure_slabs(h, g.split_k * D, g.M, g.N);
+    if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
+    pl_gemm(g, ao.cinv, h->sc_gc.ip(), ws, Hp, N4);
   }
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
@@ -1448,54 +1269,22 @@ int backward(nasr_ctx* h) {
     if (rc) return rc;
   }
   h->n_bwd_launch = 0;
-  const int NC = h->pipe_chunks;
-  if (NC <= 1) {
-    for (int l = h->L - 1; l >= 0; --l) {
-      const bool defer = h->persist && h->bucket_defer;
-      {
-        PhaseScope ps(h, PH_RECB);
-        int rc = run_steps(h, l, true, 0, T, h->st);
-        if (rc) return rc;
-        h->n_bwd_launch += h->persist ? 1 : T;
-      }
-      if (defer && l + 1 < h->L && h->bucket_of_layer[l + 1] >= 0)   // the layer above's bucket, held back over this launch
-        HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l + 1]], h->st));
-      PhaseScope ps(h, PH_WGRAD);
-      if (l > 0 || h->npre > 0) gemm_dx(h, l, 0, R, h->st, true);   // critical path first
-      int rc = weight_grads(h, l);
-      if (rc) return rc;
-      if (h->bucket_of_layer[l] >= 0 && !(defer && l > 0))
-        HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
-    }
-  } else {
-    // BPTT of layer l on chunk c needs dOut_l[chunk c] = dX GEMM of layer l+1's chunk c, and its own chunk c+1
+  for (int l = h->L - 1; l >= 0; --l) {
+    const bool defer = h->persist && h->bucket_defer;
     {
       PhaseScope ps(h, PH_RECB);
-      const int Tc = (T + NC - 1) / NC;
-      int rc = pipe_fork(h);
+      int rc = run_steps(h, l, true, 0, T, h->st);
       if (rc) return rc;
-      const int lastc = (T - 1) / Tc;
-      for (int c = lastc; c >= 0; --c) {
-        const int t0 = c * Tc, t1 = std::min(T, t0 + Tc);
-        for (int l = h->L - 1; l >= 0; --l) {
-          hipStream_t st = stream_of(h, l);
-          if (l < h->L - 1) HIPCHK(h, hipStreamWaitEvent(st, h->ev_dx[(l + 1) * PIPE_MAX_CHUNKS + c], 0));
-          rc = run_steps(h, l, true, t0, t1, st);
-          if (rc) return rc;
-          if (l > 0) gemm_dx(h, l, t0 * Bp, (t1 - t0) * Bp, st);
-          HIPCHK(h, hipEventRecord(h->ev_dx[l * PIPE_MAX_CHUNKS + c], st));
-        }
-      }
-      for (int l = 1; l < h->L; ++l) HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_dx[l * PIPE_MAX_CHUNKS + 0], 0));
-      h->n_bwd_launch = T + (h->L - 1) * Tc;
-      HIPCHK(h, hipGetLastError());
+      h->n_bwd_launch += h->persist ? 1 : T;
     }
+    if (defer && l + 1 < h->L && h->bucket_of_layer[l + 1] >= 0)   // the layer above's bucket, held back over this launch
+      HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l + 1]], h->st));
     PhaseScope ps(h, PH_WGRAD);
-    for (int l = h->L - 1; l >= 0; --l) {
-      int rc = weight_grads(h, l);
-      if (rc) return rc;
-      if (h->bucket_of_layer[l] >= 0) HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
-    }
+    if (l > 0 || h->npre > 0) gemm_dx(h, l, R, h->st);   // critical path first
+    int rc = weight_grads(h, l);
+    if (rc) return rc;
+    if (h->bucket_of_layer[l] >= 0 && !(defer && l > 0))
+      HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
   }
   for (int i = h->npre - 1; i >= 0; --i) {
     PhaseScope ps(h, PH_WGRAD);
@@ -1603,20 +1392,9 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   }
   if (build_layout(h) != NASR_OK) return bail(NASR_ERR_ARG, h->err);
   {
-    const char* e = getenv("NASR_GEMM");
-    h->gemm_bf16 = !(e && std::string(e) == "f32");
-    const char* e2 = getenv("NASR_SPLIT2");
-    h->split2 = !(e2 && e2[0] == '0');
-    // the tiled-plane copies of activations are single scratch buffers: not for the multi-stream layer pipeline
-    const char* ep = getenv("NASR_PIPE");
-    const char* es = getenv("NASR_PERSIST");
-    const bool persist_cand = !(es && es[0] == '0') && persist_supported(h->Hp) && prop.multiProcessorCount == 256;
-    const bool pipe_cand = h->D == 1 && h->L > 1 && !(ep && ep[0] == '0') && !persist_cand && h->ndense == 0;
-    h->gemm_tp = h->gemm_bf16 && !(e && std::string(e) == "bf16") && !pipe_cand;
-    h->tph = h->gemm_tp && !(e && std::string(e) == "tp3");
     h->sc_wr.resize(h->L); h->sc_wc.resize(h->L);
     h->sc_dr.resize(h->ndense); h->sc_dc.resize(h->ndense); h->sc_yr.resize(h->ndense); h->sc_yc.resize(h->ndense);
-    if (h->tph) {
+    {
       bool ok = gemm_tph_prepare() == hipSuccess, g2 = false;
       int rmax = 1, cmax = 1;
       for (int l = 0; l < h->L; ++l) {
@@ -1633,35 +1411,25 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       ok = ok && h->scws.ensure(std::max(wsf, tph_scale_ws_floats(rmax, cmax)) * 4, &g2);
       if (!ok) return bail(NASR_ERR_HIP, "set-up of the fp16-plane GEMMs failed");
     }
-    if (h->gemm_tp) {
+    {
       size_t of = 0, ob = 0;
       h->off_wftp.resize(h->L); h->off_wbtp.resize(h->L);
       for (int l = 0; l < h->L; ++l) {
-        h->off_wftp[l] = of; of += tp_bytes(h->D * h->N4, h->Ip[l]);
-        h->off_wbtp[l] = ob; if (l > 0 || h->npre > 0) ob += tp_bytes(h->Ip[l], h->D * h->N4);
+        h->off_wftp[l] = of; of += tph_bytes(h->D * h->N4, h->Ip[l]);
+        h->off_wbtp[l] = ob; if (l > 0 || h->npre > 0) ob += tph_bytes(h->Ip[l], h->D * h->N4);
       }
       size_t df = 0, db = 0;
       h->off_dftp.assign(h->ndense, 0); h->off_dbtp.assign(h->ndense, 0);
       for (int i = 0; i < h->ndense; ++i) {
-        h->off_dftp[i] = df; df += tp_bytes(h->dWp[i], h->dIp[i]);
-        h->off_dbtp[i] = db; if (i > 0 || h->npre == 0) db += tp_bytes(h->dIp[i], h->dWp[i]);
+        h->off_dftp[i] = df; df += tph_bytes(h->dWp[i], h->dIp[i]);
+        h->off_dbtp[i] = db; if (i > 0 || h->npre == 0) db += tph_bytes(h->dIp[i], h->dWp[i]);
       }
-      if (gemm_tp_prepare() != hipSuccess || hipMalloc(&h->WfTP, of) != hipSuccess ||
+      if (hipMalloc(&h->WfTP, of) != hipSuccess ||
           hipMalloc(&h->WbTP, std::max<size_t>(ob, 1024)) != hipSuccess ||
           hipMalloc(&h->DfTP, std::max<size_t>(df, 1024)) != hipSuccess ||
           hipMalloc(&h->DbTP, std::max<size_t>(db, 1024)) != hipSuccess)
         return bail(NASR_ERR_HIP, "hipMalloc of the tiled weight planes failed");
-    } else if (h->ndense) {
-      return bail(NASR_ERR_ARG, "the dense stages of the DeepSpeech family need the tiled-plane GEMMs (NASR_GEMM unset or tp)");
     }
-    int64_t o = 0;
-    h->off_wxt.resize(h->L);
-    for (int l = 0; l < h->L; ++l) {
-      h->off_wxt[l] = o;
-      o += (int64_t)h->Ip[l] * h->D * h->N4;
-    }
-    if (h->gemm_bf16 && !h->gemm_tp && hipMalloc(&h->WxT, (size_t)o * 4) != hipSuccess)
-      return bail(NASR_ERR_HIP, "hipMalloc of transposed weights failed");
   }
   const size_t nb = (size_t)h->np_int * 4;
   const size_t gb = nb + GRAD_HEAD * 4;   // the gradient buffer starts with the fault word (+ padding): see nasr_grad_device_count
@@ -1733,27 +1501,6 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   h->cbuf.resize(h->L);
   h->Ybuf.resize(h->ndense);
   h->dYbuf.resize(h->ndense);
-  {
-    // Tried and removed (measured on MI355X, 3x500 bi, B 16, T 500): running the weight-gradient GEMMs of layer l on
-    // a low-priority side stream under the BPTT of layer l-1 slowed the latency-bound BPTT launches by 30 % and the
-    // step got 0.5 ms LONGER.  What does pay is pipelining the layers of a UNIdirectional stack, whose step launches
-    // fill only half the CUs: per-layer streams, time chunks, events (NASR_PIPE=0 disables).
-    const char* e = getenv("NASR_PIPE");
-    h->pipe = h->D == 1 && h->L > 1 && !(e && e[0] == '0') && !h->persist && h->ndense == 0;
-    const size_t nl = h->pipe ? (size_t)h->L : 1;
-    h->doutL.resize(nl); h->hstateL.resize(nl); h->partialL.resize(nl); h->dcstateL.resize(nl); h->dgL.resize(nl);
-    h->lst.assign((size_t)h->L, h->st);
-    if (h->pipe) {
-      for (int l = 1; l < h->L; ++l)
-        if (hipStreamCreateWithFlags(&h->lst[l], hipStreamNonBlocking) != hipSuccess)
-          return bail(NASR_ERR_HIP, "hipStreamCreate (layer stream) failed");
-      (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-      h->ev_done.resize((size_t)h->L * PIPE_MAX_CHUNKS);
-      h->ev_dx.resize((size_t)h->L * PIPE_MAX_CHUNKS);
-      for (auto& e2 : h->ev_done) (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
-      for (auto& e2 : h->ev_dx) (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
-    }
-  }
   if (hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking) != hipSuccess) return bail(NASR_ERR_HIP, "hipStreamCreate (copy stream) failed");
   for (BatchSlot& bs : h->slots)
     if (hipEventCreateWithFlags(&bs.ev_copy, hipEventDisableTiming) != hipSuccess ||
@@ -1780,17 +1527,9 @@ int nasr_destroy(nasr_handle h) {
   if (!h) return NASR_OK;
   (void)hipSetDevice(h->device);
   if (h->st) (void)hipStreamSynchronize(h->st);
-  for (size_t l = 1; l < h->lst.size(); ++l)
-    if (h->lst[l] && h->lst[l] != h->st) {
-      (void)hipStreamSynchronize(h->lst[l]);
-      (void)hipStreamDestroy(h->lst[l]);
-    }
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  for (hipEvent_t e : h->ev_done) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->ev_dx) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_bucket) (void)hipEventDestroy(e);
   drop_graphs(h);
-  for (float* p : {h->P, h->M, h->V, h->Gbase, h->Uf, h->Ub, h->WxT, h->Upf, h->Upb, h->xch, h->Ucs, h->Ucinv})
+  for (float* p : {h->P, h->M, h->V, h->Gbase, h->Uf, h->Ub, h->Upf, h->Upb, h->xch, h->Ucs, h->Ucinv})
     if (p) (void)hipFree(p);
   if (h->WfTP) (void)hipFree(h->WfTP);
   if (h->WbTP) (void)hipFree(h->WbTP);
@@ -1818,12 +1557,10 @@ int nasr_destroy(nasr_handle h) {
     if (bs.ev_copy) (void)hipEventDestroy(bs.ev_copy);
     if (bs.ev_released) (void)hipEventDestroy(bs.ev_released);
   }
-  for (DevBuf* b : {&h->X0, &h->X0T, &h->outT0, &h->outT1, &h->dGT, &h->logits, &h->logz,
+  for (DevBuf* b : {&h->seqbuf, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->slabs,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
     b->release();
-  for (auto* v : {&h->doutL, &h->hstateL, &h->partialL, &h->dcstateL, &h->dgL})
-    for (auto& b : *v) b.release();
   for (auto& b : h->gates) b.release();
   for (auto& b : h->outb) b.release();
   for (auto& b : h->cbuf) b.release();

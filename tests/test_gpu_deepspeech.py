@@ -10,9 +10,7 @@ from oracle import nasr_oracle as O
 
 import os
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('NASR_GEMM', 'tp') in ('bf16', 'f32'),
-                                 reason='the dense stages run on the tiled-plane GEMMs only (NASR_GEMM unset or tp)')]
+pytestmark = pytest.mark.gpu
 
 
 def make_engine(spec, lr=1e-3):

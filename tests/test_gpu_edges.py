@@ -159,7 +159,7 @@ def test_device_side_context_stacking_is_bitwise_the_host_stacking():
 
 
 @pytest.mark.parametrize("spec", [O.ModelSpec(10, 32, 2, True, 'concat', 6), O.ModelSpec(10, 32, 3, False, 'none', 6)],
-                         ids=['bi2', 'uni3-pipelined'])
+                         ids=['bi2', 'uni3'])
 def test_shapes_change_between_steps(spec):
     """Real training feeds a different (B, T, Lmax) every step: buffers regrow, cached hipGraphs of a shape are reused
     when it returns, and nothing stale survives a re-allocation."""
@@ -249,3 +249,22 @@ def test_staged_batches_equal_synchronous_uploads_bitwise():
     e.discard_batch(t2)
     e.close()
     ref.close()
+
+
+def test_per_step_graphs_follow_the_resident_batch():
+    """The per-timestep fallback replays hipGraphs captured on the first batch of a shape: every later batch of that shape
+    (other lengths, another upload slot) must be what the replay reads."""
+    spec = O.ModelSpec(10, 40, 2, True, 'concat', 6)
+    params = [p.astype(np.float32).astype(np.float64) for p in O.init_params(spec, seed=7)]
+    e = engine_for(spec)
+    e.set_params(O.flatten(params))
+    e.set_recurrence_mode(False)
+    assert e.recurrence_mode == 'per-step'
+    for seed in (1, 2, 3, 4, 5):
+        feats, seq_len, labels, label_len = O.synth_batch(spec, 6, 20, seed=seed, var_len=True, Lmin=1, Lmax=3)
+        loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+        lo, nllo, go, _ = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+        assert loss == pytest.approx(lo, rel=3e-5), seed
+        np.testing.assert_allclose(nll, nllo, rtol=3e-5)
+        assert rel(grads, O.flatten(go)) < 1e-4
+    e.close()

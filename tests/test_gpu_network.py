@@ -13,8 +13,6 @@ from oracle import nasr_oracle as O
 pytestmark = pytest.mark.gpu
 needs_persistent = pytest.mark.skipif(os.environ.get('NASR_PERSIST', '1')[:1] == '0',
                                       reason='asserts the persistent recurrence; NASR_PERSIST=0 forces the per-step kernels')
-needs_tp = pytest.mark.skipif(os.environ.get('NASR_GEMM', 'tp') in ('bf16', 'f32'),
-                              reason='the DeepSpeech dense stages run on the tiled-plane GEMMs only')
 HERE = os.path.dirname(os.path.abspath(__file__))
 SAMPLES = os.path.join(HERE, 'golden', 'sample_set')
 
@@ -276,7 +274,6 @@ def test_rccl_path_at_world_one_orders_with_the_engine_stream(tmp_path):
 
 
 @needs_persistent
-@needs_tp
 def test_deepspeech_plugin_trains_and_validates(tmp_path, monkeypatch):
     """`network=networks.deepspeech.DeepSpeech` resolves to the HIP class (reference: networks/deepspeech.py); run at
     reduced widths so the toy set trains in a blink: variable names / shapes in the reference's creation order, initial

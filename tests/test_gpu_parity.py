@@ -42,7 +42,7 @@ CASES = [
     (O.ModelSpec(10, 16, 1, True, 'stack_reshape', 4), 1, 12, False),
     (O.ModelSpec(12, 20, 1, True, 'concat', 6), 20, 15, True),      # two M tiles
     (O.ModelSpec(12, 20, 2, False, 'none', 40), 33, 10, True),      # three M tiles, C > 32
-    (O.ModelSpec(11, 32, 3, False, 'none', 6), 4, 75, True),        # T >= 64: the uni stack is pipelined over 2 chunks
+    (O.ModelSpec(11, 32, 3, False, 'none', 6), 4, 75, True),        # a 3-layer unidirectional stack, T >= 64
     (O.ModelSpec(11, 24, 2, False, 'none', 6), 5, 133, True),       # 4 chunks, ragged last chunk
 ]
 

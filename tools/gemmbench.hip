@@ -1,8 +1,6 @@
 // gemmbench.hip — times the GEMM shapes of the training step (B 16, T 500, H 500, F 546).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DNASR_GEMM_BK=..] tools/gemmbench.hip -o tools/sb_gemm
 #include "../neuralasr_amd/csrc/gemm.hip"
-#include "../neuralasr_amd/csrc/gemm_bf16.hip"
-#include "../neuralasr_amd/csrc/gemm_tp.hip"
 #include "../neuralasr_amd/csrc/gemm_tph.hip"
 #include "../neuralasr_amd/csrc/optim.hip"
 #include <cmath>
@@ -47,7 +45,7 @@ int main() {
     double fl = 2.0 * c.g.M * c.g.N * c.g.K;
     printf("%s split %d : %.3f ms  %.1f TF\n", c.name, c.g.split_k, best, fl / best / 1e9);
   }
-  // ---- bf16x6 NT kernel: numerics vs the fp32 kernel (same data, NT form) and speed
+  // ---- the shapes of the step in NT form (A [M][K], B [N][K]): operands are views of the buffers above
   struct NT { const char* name; int M, N, K, split; const float* A; size_t a_elems; const float* B; size_t b_elems; };
   const size_t nX = (size_t)R * 1024, nG = (size_t)R * 4096, nW = (size_t)1024 * 4096;
   std::vector<NT> nts = {{"xproj  NT 8000x4096x576 ", R, 4096, 576, 1, X, nX, W, nW}, {"xproj  NT 8000x4096x1024", R, 4096, 1024, 1, X, nX, W, nW},
@@ -55,61 +53,6 @@ int main() {
                          {"dWx    NT 1024x4096x8000", 1024, 4096, R, 2, X, nX, G, nG}, {"dU     NT 512x2048x8000 ", 512, 2048, R, 8, X, nX, G, nG},
                          {"odd    NT 1100x1024x4096", 1100, 1024, 4096, 1, G, nG, W, nW}};   // 192-row tiles, ragged last block row
   float* O2 = dev_rand((size_t)R * 4096);
-  for (auto& c : nts) {
-    // operands: A [M][K] = X viewed with lda = K, B [N][K] = G viewed with ldb = K (both buffers are large enough)
-    if ((size_t)c.M * c.K > c.a_elems || (size_t)c.N * c.K > c.b_elems || (size_t)c.M * c.N > nG ||
-        (size_t)c.split * c.M * c.N > (size_t)8 * 1024 * 4096) { printf("%s: operand does not fit its buffer, skipped\n", c.name); continue; }
-    GemmNTDesc g{}; g.A = c.A; g.B = c.B; g.C = O; g.M = c.M; g.N = c.N; g.K = c.K; g.lda = c.K; g.ldb = c.K; g.ldc = c.N;
-    g.split_k = c.split; g.slabs = slabs;
-    GemmDesc f{}; f.A = c.A; f.B = c.B; f.C = O2; f.M = c.M; f.N = c.N; f.K = c.K; f.lda = c.K; f.ldb = c.K; f.ldc = c.N;
-    f.b_col = true; f.a_rows = c.M; f.split_k = 1;
-    launch_gemm_nt(g, st); launch_gemm(f, st); CK(hipStreamSynchronize(st));
-    std::vector<float> h1((size_t)c.M * c.N), h2((size_t)c.M * c.N);
-    CK(hipMemcpy(h1.data(), O, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), O2, h2.size() * 4, hipMemcpyDeviceToHost));
-    double num = 0, den = 0, mx = 0;
-    for (size_t i = 0; i < h1.size(); ++i) { double d = (double)h1[i] - h2[i]; num += d * d; den += (double)h2[i] * h2[i]; if (fabs(d) > mx) mx = fabs(d); }
-    float best = 1e9f;
-    for (int i = 0; i < 10; ++i) {
-      CK(hipEventRecord(a, st)); launch_gemm_nt(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
-    }
-    printf("bf16x6 %s split %d : %.3f ms  %.1f TF-equiv   rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, c.split, best,
-           2.0 * c.M * c.N * c.K / best / 1e9, sqrt(num / den), mx);
-  }
-  // ---- tiled-plane kernel (gemm_tp.hip): split passes + GEMM, numerics vs the fp32 kernel
-  CK(gemm_tp_prepare());
-  unsigned char *TA, *TB;
-  CK(hipMalloc(&TA, tp_bytes(R, 4096))); CK(hipMalloc(&TB, tp_bytes(4096, R)));
-  for (auto& c : nts) {
-    if ((size_t)c.M * c.K > c.a_elems || (size_t)c.N * c.K > c.b_elems) continue;
-    const int split = gemm_tp_pick_split(c.M, c.N, c.K);
-    GemmDesc f{}; f.A = c.A; f.B = c.B; f.C = O2; f.M = c.M; f.N = c.N; f.K = c.K; f.lda = c.K; f.ldb = c.K; f.ldc = c.N;
-    f.b_col = true; f.a_rows = c.M; f.split_k = 1;
-    launch_gemm(f, st);
-    float tsplit = 1e9f;
-    for (int i = 0; i < 3; ++i) {
-      CK(hipEventRecord(a, st));
-      launch_tp_split(c.A, TA, c.M, c.K, c.K, false, st); launch_tp_split(c.B, TB, c.N, c.K, c.K, false, st);
-      CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b)); tsplit = ms < tsplit ? ms : tsplit;
-    }
-    GemmTPDesc g{}; g.A = TA; g.B = TB; g.C = O; g.M = c.M; g.N = c.N; g.K = c.K; g.nkbA = (c.K + 15) / 16; g.nkbB = g.nkbA; g.ldc = c.N;
-    g.split_k = split; g.slabs = slabs;
-    if ((size_t)split * c.M * c.N > (size_t)8 * 1024 * 4096) { printf("slabs too small\n"); continue; }
-    CK(hipMemset(O, 0xff, (size_t)c.M * c.N * 4));
-    launch_gemm_tp(g, st); CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-    std::vector<float> h1((size_t)c.M * c.N), h2((size_t)c.M * c.N);
-    CK(hipMemcpy(h1.data(), O, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), O2, h2.size() * 4, hipMemcpyDeviceToHost));
-    double num = 0, den = 0, mx = 0;
-    for (size_t i = 0; i < h1.size(); ++i) { double d = (double)h1[i] - h2[i]; num += d * d; den += (double)h2[i] * h2[i]; if (!(fabs(d) <= mx)) mx = fabs(d); }
-    float best = 1e9f;
-    for (int i = 0; i < 10; ++i) {
-      CK(hipEventRecord(a, st)); launch_gemm_tp(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
-    }
-    printf("tp     %s split %d : %.3f ms  %.1f TF-equiv (+ %.3f ms to split both operands)  rel-L2 vs f32 kernel %.2e  max abs %.2e\n", c.name, split, best,
-           2.0 * c.M * c.N * c.K / best / 1e9, tsplit, sqrt(num / den), mx);
-  }
   // ---- two fp16 planes + three products (gemm_tph.hip): the same shapes, operands scaled per row from measured maxima
   {
     CK(gemm_tph_prepare());
@@ -221,88 +164,5 @@ int main() {
     printf("fp16 planes of a 960x1000 matrix spanning 2^-20..2^20: %d / %d bad row / column scales, column sums rel %.1e, worst element error / bound max(2^-24 |x|, 2^-40 line max): %.2f (row-scaled planes) %.2f (column-scaled planes)\n",
            badr, badc, sqrt(se / sn), worst_n, worst_t);
   }
-  // block-tile height x K split for the layer-0 weight gradient (M = 576 = 2.25 x 256 = 3 x 192)
-  {
-    launch_tp_split(X, TA, 576, R, R, false, st); launch_tp_split(G, TB, 4096, R, R, false, st);
-    for (int tm : {256, 192})
-      for (int split : {4, 5, 6, 8, 10}) {
-        GemmTPDesc g{}; g.A = TA; g.B = TB; g.C = O; g.M = 576; g.N = 4096; g.K = R; g.nkbA = (R + 15) / 16; g.nkbB = g.nkbA; g.ldc = 4096;
-        g.split_k = split; g.slabs = slabs; g.tile_rows = tm;
-        launch_gemm_tp(g, st); CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-        float best = 1e9f;
-        for (int i = 0; i < 10; ++i) {
-          CK(hipEventRecord(a, st)); launch_gemm_tp(g, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-          float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
-        }
-        printf("sweep  dWx 576x4096x8000 tile rows %d split %2d : %.3f ms\n", tm, split, best);
-      }
-  }
-  // fused split: both plane sets from one pass must equal the two separate passes, byte for byte (also on ragged sizes)
-  for (int rr : {R, 7993}) for (int kk : {4096, 1000}) {
-    unsigned char *N1, *N2, *T1, *T2;
-    const size_t bn = tp_bytes(rr, kk), bt = tp_bytes(kk, rr);
-    CK(hipMalloc(&N1, bn)); CK(hipMalloc(&N2, bn)); CK(hipMalloc(&T1, bt)); CK(hipMalloc(&T2, bt));
-    CK(hipMemset(N2, 0xee, bn)); CK(hipMemset(T2, 0xee, bt));
-    launch_tp_split(G, N1, rr, kk, 4096, false, st); launch_tp_split(G, T1, kk, rr, 4096, true, st);
-    launch_tp_split2(G, N2, T2, rr, kk, 4096, nullptr, st);
-    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-    std::vector<unsigned char> a1(bn), a2(bn), b1(bt), b2(bt);
-    CK(hipMemcpy(a1.data(), N1, bn, hipMemcpyDeviceToHost)); CK(hipMemcpy(a2.data(), N2, bn, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(b1.data(), T1, bt, hipMemcpyDeviceToHost)); CK(hipMemcpy(b2.data(), T2, bt, hipMemcpyDeviceToHost));
-    size_t badn = 0, badt = 0;
-    for (size_t i = 0; i < bn; ++i) badn += a1[i] != a2[i];
-    for (size_t i = 0; i < bt; ++i) badt += b1[i] != b2[i];
-    float t1 = 1e9f, t2 = 1e9f;
-    for (int i = 0; i < 5; ++i) {
-      CK(hipEventRecord(a, st)); launch_tp_split(G, N1, rr, kk, 4096, false, st); launch_tp_split(G, T1, kk, rr, 4096, true, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b)); t1 = ms < t1 ? ms : t1;
-      CK(hipEventRecord(a, st)); launch_tp_split2(G, N2, T2, rr, kk, 4096, nullptr, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-      CK(hipEventElapsedTime(&ms, a, b)); t2 = ms < t2 ? ms : t2;
-    }
-    printf("fused split %dx%d: %zu / %zu differing bytes (normal / transposed planes); two passes %.3f ms, one pass %.3f ms\n", rr, kk, badn, badt, t1, t2);
-    CK(hipFree(N1)); CK(hipFree(N2)); CK(hipFree(T1)); CK(hipFree(T2));
-  }
-  {  // the fused pass and its options on dG [8000][4096]
-    unsigned char *N2, *T2; float* cp;
-    CK(hipMalloc(&N2, tp_bytes(R, 4096))); CK(hipMalloc(&T2, tp_bytes(4096, R))); CK(hipMalloc(&cp, (size_t)tp_split2_parts(R) * 4096 * 4));
-    struct V { const char* name; bool n, c; } vs[] = {{"both planes", true, false}, {"both planes + column sums", true, true},
-                                                      {"transposed only", false, false}, {"transposed only + column sums", false, true}};
-    for (auto& v : vs) {
-      float best = 1e9f;
-      for (int i = 0; i < 6; ++i) {
-        CK(hipEventRecord(a, st)); launch_tp_split2(G, v.n ? N2 : nullptr, T2, R, 4096, 4096, v.c ? cp : nullptr, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-        float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
-      }
-      printf("fused pass, %s: %.3f ms\n", v.name, best);
-    }
-    float best = 1e9f;
-    for (int i = 0; i < 6; ++i) {
-      CK(hipEventRecord(a, st)); launch_colsum(G, R, 4096, 4096, O2, cp, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
-    }
-    printf("separate column-sum pass: %.3f ms\n", best);
-    best = 1e9f;
-    for (int i = 0; i < 6; ++i) {
-      CK(hipEventRecord(a, st)); launch_colsum_parts(cp, tp_split2_parts(R), 4096, O2, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
-      float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
-    }
-    printf("sum of the fused pass's %d partial rows: %.3f ms\n", tp_split2_parts(R), best);
-  }
-  // transposed split: TP from a [K][rows] source must equal TP from the explicit transpose
-  {
-    launch_transpose(G, O2, R, 4096, 4096, R, st);                 // O2 = G^T [4096][R]
-    launch_tp_split(O2, TB, 4096, R, R, false, st);
-    unsigned char* TC; CK(hipMalloc(&TC, tp_bytes(4096, R)));
-    launch_tp_split(G, TC, 4096, R, 4096, true, st);
-    CK(hipStreamSynchronize(st));
-    std::vector<unsigned char> u1(tp_bytes(4096, R)), u2(tp_bytes(4096, R));
-    CK(hipMemcpy(u1.data(), TB, u1.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(u2.data(), TC, u2.size(), hipMemcpyDeviceToHost));
-    size_t bad = 0; for (size_t i = 0; i < u1.size(); ++i) bad += u1[i] != u2[i];
-    float best = 1e9f; for (int i = 0; i < 5; ++i) { CK(hipEventRecord(a, st)); launch_tp_split(G, TC, 4096, R, 4096, true, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; }
-    printf("transposed split 8000x4096 -> TP[4096][8000]: %zu differing bytes vs transpose+split, %.3f ms\n", bad, best);
-  }
-  // transpose
-  { float best = 1e9f; for (int i = 0; i < 5; ++i) { CK(hipEventRecord(a, st)); launch_transpose(G, O, R, 4096, 4096, R, st); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; }
-    printf("transpose 8000x4096: %.3f ms\n", best); }
   return 0;
 }
