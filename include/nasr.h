@@ -208,6 +208,18 @@ int nasr_get_loss(nasr_handle h, float* loss_out);    /* synchronises; loss of l
  * every rank and the caller should run the step again (a rank whose persistent recurrence aborted has switched to the
  * per-step kernels by then).  Call it after nasr_apply_adam on every rank: all ranks get the same answer. */
 int nasr_step_void(nasr_handle h, int* void_out);
+/* The values Network.train returns (tfnetwork.py:183-190: loss, and the decode the LER is computed from) are known after
+ * the forward pass and the CTC kernels; the backward pass, the gradient exchange and Adam need not be waited for.  With
+ * nasr_set_step_decode(1) every nasr_compute_grads copies the loss, the fault word as it stands after the forward pass and
+ * the greedy decode (ids [B][T'] row-major, lens [B]) to pinned host memory right behind the CTC kernels;
+ * nasr_get_step_results waits for THAT copy only.  A host that returns from train() at this point enqueues the next
+ * step while the device still runs the backward pass of this one: the device never waits for the host.  fault_out = 1:
+ * this rank's forward recurrence aborted, the values are meaningless (then use nasr_step_void and repeat the step).
+ * nasr_settle_step(h, previous, &v) waits for the END of the latest (previous = 0) or the one-before-latest (1) step
+ * that reached nasr_apply_adam and says whether it was void (on every rank: the fault word is all-reduced with the
+ * gradients); a void step's Adam launch was a no-op and is taken out of the step count. */
+int nasr_get_step_results(nasr_handle h, float* loss_out, int* fault_out, int32_t* ids_out, int32_t* lens_out);
+int nasr_settle_step(nasr_handle h, int previous, int* void_out);
 int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the resident batch */
 
 /* TensorFlowNetwork.train fetches mean_ler with every step (networks/tfnetwork.py:188-189): with

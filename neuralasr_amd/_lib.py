@@ -29,7 +29,7 @@ SYMBOLS = [
     'nasr_get_recurrence_mode', 'nasr_set_recurrence_mode', 'nasr_set_dropout_state', 'nasr_get_dropout_state',
     'nasr_step_void', 'nasr_get_persist_stats', 'nasr_stage_batch', 'nasr_stage_batch_context', 'nasr_commit_batch',
     'nasr_discard_batch', 'nasr_set_bucket_defer', 'nasr_comm_unique_id', 'nasr_comm_init', 'nasr_comm_size',
-    'nasr_comm_allreduce_grads', 'nasr_comm_mean', 'nasr_comm_destroy',
+    'nasr_comm_allreduce_grads', 'nasr_comm_mean', 'nasr_comm_destroy', 'nasr_get_step_results', 'nasr_settle_step',
 ]
 
 
@@ -131,6 +131,8 @@ def load():
         'nasr_comm_allreduce_grads': (c_int, [H]),
         'nasr_comm_mean': (c_int, [H, fp, c_int]),
         'nasr_comm_destroy': (c_int, [H]),
+        'nasr_get_step_results': (c_int, [H, fp, POINTER(c_int), ip, ip]),
+        'nasr_settle_step': (c_int, [H, c_int, POINTER(c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -153,8 +153,10 @@ void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, in
                    hipStream_t st);
 
 // ---- optimiser / reductions (optim.hip) ----
-// fault: device word (or NULL); a non-zero value makes the launch a no-op (see optim.hip)
-void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr_t, float beta1, float beta2,
+// Adam's step count and the step size derived from it, on the device: a launch whose `fault` word (device float, or NULL)
+// is non-zero is a no-op AND leaves the count alone, so a void step never enters the bias correction.
+struct AdamDev { long long step; float lr_t; int applied; };
+void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, AdamDev* state, float lr, float beta1, float beta2,
                  float eps, float gscale, const float* fault, hipStream_t st);
 // out[n] = sum_r M[r*ld + n], deterministic two-stage; ws holds 32*N floats
 void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st);

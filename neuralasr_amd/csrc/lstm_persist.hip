@@ -694,7 +694,7 @@ bool persist_supported(int Hp) {
   return Hp % 64 == 0 && NU >= 2 && NU <= 16;   // every padded hidden size up to 512
 }
 
-static PersistGeom make_geom(const LstmDims& dm) {
+static PersistGeom make_geom(const LstmDims& dm, bool bwd) {
   PersistGeom g;
   g.T = dm.T; g.Bp = dm.Bp; g.Hp = dm.Hp; g.D = dm.D;
   const int NGD = 8 / dm.D;
@@ -703,6 +703,8 @@ static PersistGeom make_geom(const LstmDims& dm) {
   g.rounds = (dm.Bp + NGD * g.ub - 1) / (NGD * g.ub);
   const char* e = getenv("NASR_PERSIST_FAULT");
   g.inject = (e && *e) ? atoi(e) : -1;
+  const char* ek = getenv("NASR_PERSIST_FAULT_KERNEL");     // "fwd" / "bwd": inject into that kernel only
+  if (ek && *ek && ((ek[0] == 'b') != bwd)) g.inject = -1;
   g.fault = nullptr;
   return g;
 }
@@ -732,7 +734,7 @@ hipError_t persist_prepare() {
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* cinv, float* gates, float* cbuf,
                              float* out, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
                              float forget_bias, hipStream_t st, bool ctl_zeroed) {
-  PersistGeom gm = make_geom(dm);
+  PersistGeom gm = make_geom(dm, false);
   gm.fault = fault;
   if (!ctl_zeroed) (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(320);
@@ -759,7 +761,7 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* 
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
                              float* fault, hipStream_t st, bool ctl_zeroed) {
-  PersistGeom gm = make_geom(dm);
+  PersistGeom gm = make_geom(dm, true);
   gm.fault = fault;
   if (!ctl_zeroed) (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
   dim3 grid(256), block(320);

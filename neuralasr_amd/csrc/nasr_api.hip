@@ -4,6 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <sched.h>
+#include <unistd.h>
+
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -112,7 +116,6 @@ struct nasr_ctx {
   bool persist = false;
   bool persist_ok = false;             // the device passed the census at create time
   bool persist_used = false;           // a persistent launch is in flight since the last check of *perr
-  int adam_unverified = 0;             // 1: an Adam launch followed the compute_grads whose fault word is still unread
   // re-arming the persistent recurrence after an abort (persist_check): the per-step kernels serve `rearm_after` clean
   // steps, then the census of nasr_create runs again and, if it passes, the persistent kernels come back; every further
   // abort doubles the wait.  NASR_PERSIST_REARM sets the first wait (0 = never re-arm).
@@ -187,8 +190,21 @@ struct nasr_ctx {
   // weight_grads(l), so that a collective released by it co-runs with the GEMM phase of layer l-1, not with the launch
   // that wants every CU's memory queue to itself (nasr_set_bucket_defer; NASR_BUCKET_DEFER=0 at create).
   bool bucket_defer = true;
-  int64_t adam_step = 0;
+  // Adam's step count t lives ON THE DEVICE (AdamDev, optim.hip): the launch that finds the step's fault word set leaves
+  // it alone, so a void step never enters the bias correction - whenever the host learns about it.
+  AdamDev* adam_dev = nullptr;
   float lr;
+  // Results of a step without waiting for its end (nasr_get_step_results): loss, the fault word as it stands after the
+  // forward pass, and the greedy decode are copied to pinned memory right behind the CTC forward kernels; the fault
+  // word at the END of a step is copied behind its Adam launch (nasr_settle_step).  Two slots each: the host may be
+  // one step ahead of the device.
+  struct StepRes { void* host = nullptr; size_t cap = 0; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int B = 0, Bp = 0, Tp = 0; };
+  StepRes res[2];
+  int res_cur = 0;
+  struct StepEnd { float* host = nullptr; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; };
+  StepEnd endw[2];
+  int end_cur = 0;
+  uint32_t stamp_seq = 0;
 
   // resident batch
   bool resident = false, have_grads = false, have_fwd = false;
@@ -345,6 +361,30 @@ void persist_rearm(nasr_ctx* h) {
   h->persist_ok = true;
   h->persist_rearms += 1;
   drop_graphs(h);
+}
+
+// A word in host-mapped pinned memory, written by a one-thread kernel in stream order (system-scope store): the host
+// learns that everything enqueued before it has happened by READING MEMORY - no runtime call, no event.  (Waiting on a HIP
+// event recorded a whole step earlier cost 0.4-0.75 ms per call here although the event had long fired.)
+__global__ void stamp_kernel(unsigned* dst, unsigned value, float* f0_dst, const float* f0_src) {
+  if (f0_dst) __hip_atomic_store(f0_dst, *f0_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(dst, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+bool wait_stamp(const uint32_t* w, uint32_t want, double timeout_s) {
+  const volatile uint32_t* v = w;
+  for (int i = 0; i < 4000; ++i)
+    if (*v == want) return true;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned n = 0;; ++n) {
+    if (*v == want) return true;
+    if ((n & 63) == 63) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+      usleep(20);
+    } else {
+      sched_yield();
+    }
+  }
 }
 
 int sync_checked(nasr_ctx* h) {
@@ -1102,7 +1142,6 @@ int forward(nasr_ctx* h) {
   // the fault word of the pass that starts here (a training step or a forward-only call); what an unread earlier word
   // said is gone with it
   HIPCHK(h, hipMemsetAsync(h->Gbase, 0, GRAD_HEAD * 4, h->st));
-  h->adam_unverified = 0;
   // the control blocks of this pass's persistent launches, cleared in one go (one per layer: run_steps)
   if (h->persist) HIPCHK(h, hipMemsetAsync(h->pctl + 1, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
   for (int i = 0; i < h->npre; ++i) {
@@ -1169,6 +1208,19 @@ int ctc_forward(nasr_ctx* h) {
     launch_greedy(d, h->logits.as<float>(), h->seq_p, h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
                   h->st);
     h->have_decoded = true;
+    // what Network.train returns is known HERE, before the backward pass: copy it out now (nasr_get_step_results)
+    h->res_cur ^= 1;
+    nasr_ctx::StepRes& r = h->res[h->res_cur];
+    const size_t bytes = 8 + (size_t)h->Bp * 4 + (size_t)h->B * h->Tp * 4;
+    if (!pinned_ensure(&r.host, &r.cap, bytes)) return h->fail(NASR_ERR_HIP, "hipHostMalloc of the step results failed");
+    char* hp = static_cast<char*>(r.host);
+    HIPCHK(h, hipMemcpyAsync(hp, h->loss.p, 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipMemcpyAsync(hp + 4, h->Gbase, 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipMemcpyAsync(hp + 8, h->lens.p, (size_t)h->Bp * 4, hipMemcpyDeviceToHost, h->st));
+    HIPCHK(h, hipMemcpyAsync(hp + 8 + (size_t)h->Bp * 4, h->ids.p, (size_t)h->B * h->Tp * 4, hipMemcpyDeviceToHost, h->st));
+    r.seq = ++h->stamp_seq;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, h->st, r.stamp, r.seq, (float*)nullptr, (const float*)nullptr);
+    r.valid = true; r.B = h->B; r.Bp = h->Bp; r.Tp = h->Tp;
   }
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
@@ -1437,6 +1489,8 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   if (hipMalloc(&h->P, nb) != hipSuccess || hipMalloc(&h->M, nb) != hipSuccess || hipMalloc(&h->V, nb) != hipSuccess ||
       hipMalloc(&h->Gbase, gb) != hipSuccess || hipMalloc(&h->Uf, ub) != hipSuccess || hipMalloc(&h->Ub, ub) != hipSuccess)
     return bail(NASR_ERR_HIP, "hipMalloc of parameter buffers failed");
+  if (hipMalloc(&h->adam_dev, sizeof(AdamDev)) != hipSuccess) return bail(NASR_ERR_HIP, "hipMalloc of the Adam state failed");
+  (void)hipMemsetAsync(h->adam_dev, 0, sizeof(AdamDev), h->st);
   (void)hipMemsetAsync(h->P, 0, nb, h->st);
   (void)hipMemsetAsync(h->M, 0, nb, h->st);
   (void)hipMemsetAsync(h->V, 0, nb, h->st);
@@ -1506,6 +1560,18 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     if (hipEventCreateWithFlags(&bs.ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&bs.ev_released, hipEventDisableTiming) != hipSuccess)
       return bail(NASR_ERR_HIP, "hipEventCreate failed");
+  for (auto& r : h->res) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&r.stamp), 64, hipHostMallocMapped) != hipSuccess)
+      return bail(NASR_ERR_HIP, "set-up of the step-result stamps failed");
+    *r.stamp = 0;
+  }
+  for (auto& e : h->endw) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&e.host), 64, hipHostMallocMapped) != hipSuccess)
+      return bail(NASR_ERR_HIP, "set-up of the step-end words failed");
+    e.stamp = reinterpret_cast<uint32_t*>(e.host) + 8;
+    *e.host = 0.f;
+    *e.stamp = 0;
+  }
   (void)hipEventCreate(&h->ev_total_a);
   (void)hipEventCreate(&h->ev_total_b);
   memset(&h->last_times, 0, sizeof(h->last_times));
@@ -1545,6 +1611,13 @@ int nasr_destroy(nasr_handle h) {
   for (auto* vec : {&h->sc_yr, &h->sc_yc, &h->sc_wr, &h->sc_wc, &h->sc_dr, &h->sc_dc})
     for (auto& v : *vec) v.release();
   (void)nasr_comm_destroy(h);
+  if (h->adam_dev) (void)hipFree(h->adam_dev);
+  for (auto& r : h->res) {
+    if (r.host) (void)hipHostFree(r.host);
+    if (r.stamp) (void)hipHostFree(r.stamp);
+  }
+  for (auto& e : h->endw)
+    if (e.host) (void)hipHostFree(e.host);
   if (h->cst) {
     (void)hipStreamSynchronize(h->cst);
     (void)hipStreamDestroy(h->cst);
@@ -1624,7 +1697,9 @@ int nasr_set_adam_state(nasr_handle h, const float* m, const float* v, int64_t n
   if (rc) return rc;
   rc = scatter_to_device(h, v, h->V);
   if (rc) return rc;
-  h->adam_step = step;
+  const AdamDev init{(long long)step, 0.f, 0};
+  HIPCHK(h, hipMemcpyAsync(h->adam_dev, &init, sizeof(init), hipMemcpyHostToDevice, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
   return NASR_OK;
 }
 
@@ -1635,7 +1710,12 @@ int nasr_get_adam_state(nasr_handle h, float* m, float* v, int64_t n, int64_t* s
   int rc = NASR_OK;
   if (m) rc = gather_from_device(h, h->M, m);
   if (!rc && v) rc = gather_from_device(h, h->V, v);
-  if (step) *step = h->adam_step;
+  if (step) {
+    AdamDev d{};
+    HIPCHK(h, hipMemcpyAsync(&d, h->adam_dev, sizeof(d), hipMemcpyDeviceToHost, h->st));
+    if (int rc2 = sync_checked(h)) return rc2;
+    *step = d.step;
+  }
   return rc;
 }
 
@@ -1740,15 +1820,16 @@ int nasr_apply_adam(nasr_handle h, float grad_scale) {
   HIPCHK(h, hipSetDevice(h->device));
   {
     PhaseScope ps(h, PH_ADAM);
-    h->adam_step += 1;
-    h->adam_unverified = 1;
-    const double b1 = h->cfg.beta1, b2 = h->cfg.beta2;
-    const double lr_t = (double)h->lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_step)) /
-                        (1.0 - std::pow(b1, (double)h->adam_step));
-    launch_adam(h->P, h->M, h->V, h->G, h->np_int, (float)lr_t, h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, grad_scale,
+    launch_adam(h->P, h->M, h->V, h->G, h->np_int, h->adam_dev, h->lr, h->cfg.beta1, h->cfg.beta2, h->cfg.epsilon, grad_scale,
                 h->Gbase, h->st);
     int rc = repack(h);
     if (rc) return rc;
+    // the step's fault word as it stands now (all-reduced with the gradients): read later, without a stream sync
+    h->end_cur ^= 1;
+    nasr_ctx::StepEnd& e = h->endw[h->end_cur];
+    e.seq = ++h->stamp_seq;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, h->st, e.stamp, e.seq, e.host, (const float*)h->Gbase);
+    e.valid = true;
   }
   if (h->profiling && h->window_open) {
     (void)hipEventRecord(h->ev_total_b, h->st);
@@ -1818,14 +1899,10 @@ int nasr_get_loss(nasr_handle h, float* loss_out) {
   HIPCHK(h, hipMemcpyAsync(&fault, h->Gbase, 4, hipMemcpyDeviceToHost, h->st));
   const int rc = sync_checked(h);
   if (fault != 0.f) {
-    // the word belongs to the LAST compute_grads: exactly one Adam launch (if any followed it) was a no-op
-    h->adam_step -= std::min<int64_t>(h->adam_unverified, h->adam_step);
-    h->adam_unverified = 0;
     if (rc) return rc;
     return h->fail(NASR_ERR_HIP, "this training step is void: the persistent recurrence of another rank aborted; no "
                                  "parameters were changed on any rank");
   }
-  h->adam_unverified = 0;
   return rc;
 }
 
@@ -1836,8 +1913,36 @@ int nasr_step_void(nasr_handle h, int* void_out) {
   HIPCHK(h, hipStreamSynchronize(h->st));
   (void)persist_check(h);   // a local abort: switch this handle to the per-step kernels (the message stays in last_error)
   *void_out = fault != 0.f ? 1 : 0;
-  if (fault != 0.f) h->adam_step -= std::min<int64_t>(h->adam_unverified, h->adam_step);
-  h->adam_unverified = 0;
+  return NASR_OK;
+}
+
+int nasr_get_step_results(nasr_handle h, float* loss_out, int* fault_out, int32_t* ids_out, int32_t* lens_out) {
+  if (!h) return NASR_ERR_ARG;
+  nasr_ctx::StepRes& r = h->res[h->res_cur];
+  if (!r.valid) return h->fail(NASR_ERR_STATE, "nasr_get_step_results: no step with nasr_set_step_decode(1) has been enqueued");
+  // the forward pass + CTC of the step; its backward pass may still run
+  if (!wait_stamp(r.stamp, r.seq, 60.0)) return h->fail(NASR_ERR_HIP, "nasr_get_step_results: the step's results did not arrive within 60 s");
+  const char* hp = static_cast<const char*>(r.host);
+  float fault;
+  memcpy(&fault, hp + 4, 4);
+  if (loss_out) memcpy(loss_out, hp, 4);
+  if (fault_out) *fault_out = fault != 0.f ? 1 : 0;
+  if (lens_out) memcpy(lens_out, hp + 8, (size_t)r.B * 4);
+  if (ids_out) memcpy(ids_out, hp + 8 + (size_t)r.Bp * 4, (size_t)r.B * r.Tp * 4);
+  return NASR_OK;
+}
+
+int nasr_settle_step(nasr_handle h, int previous, int* void_out) {
+  if (!h || !void_out) return NASR_ERR_ARG;
+  *void_out = 0;
+  nasr_ctx::StepEnd& e = h->endw[previous ? h->end_cur ^ 1 : h->end_cur];
+  if (!e.valid) return NASR_OK;
+  // the end of THAT step only
+  if (!wait_stamp(e.stamp, e.seq, 60.0)) return h->fail(NASR_ERR_HIP, "nasr_settle_step: the step did not end within 60 s");
+  if (*e.host != 0.f) {
+    *void_out = 1;
+    (void)persist_check(h);   // a local abort: this handle continues on the per-step kernels (message in last_error)
+  }
   return NASR_OK;
 }
 

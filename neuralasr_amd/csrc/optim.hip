@@ -2,7 +2,7 @@
 // reductions (bias column sums, slab sums).
 //
 // tf.train.AdamOptimizer (networks/tfnetwork.py:116-117,139):
-//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;
+//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (t counted and lr_t computed on the device);  m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;
 //   p <- p - lr_t * m / (sqrt(v) + eps)          (eps NOT bias-corrected)
 // `gscale` folds average_gradients' 1/num_towers (networks/tfnetwork.py:72-86) into the same pass.
 // One pass reads g,m,v,p and writes m,v,p with 16-byte accesses: 28 B/param, HBM-bound.
@@ -10,12 +10,26 @@
 
 namespace nasr {
 
+// t <- t + 1 and lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in double, by one thread, unless the step is void
+__global__ void adam_prepare_kernel(AdamDev* st, const float* __restrict__ fault, float lr, float b1, float b2) {
+  if (fault && *fault != 0.f) {
+    st->applied = 0;
+    return;
+  }
+  const long long t = st->step + 1;
+  st->step = t;
+  st->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+  st->applied = 1;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                                   const float* __restrict__ g, int64_t n4, float lr_t, float b1,
-                                                   float b2, float eps, float gscale, const float* __restrict__ fault) {
+                                                   const float* __restrict__ g, int64_t n4, const AdamDev* __restrict__ st,
+                                                   float b1, float b2, float eps, float gscale,
+                                                   const float* __restrict__ fault) {
   // A persistent-recurrence launch that gave up marks the gradient buffer's fault word (it is all-reduced with the
   // gradients, so every rank sees it): such a step must not touch the parameters, on any rank.
   if (fault && *fault != 0.f) return;
+  const float lr_t = st->lr_t;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 gg = reinterpret_cast<const float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i];
@@ -36,12 +50,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
-void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr_t, float beta1, float beta2,
+void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, AdamDev* state, float lr, float beta1, float beta2,
                  float eps, float gscale, const float* fault, hipStream_t st) {
   const int64_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, m, v, g, n4, lr_t, beta1, beta2, eps, gscale, fault);
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, state, fault, lr, beta1, beta2);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, m, v, g, n4, state, beta1, beta2, eps, gscale, fault);
 }
 
 // ---- column sums: stage 1 writes part[rs][n] for 32 row slices, stage 2 adds them in order

@@ -78,11 +78,17 @@ class DataSet:
             self.index += 1
         max_time = max(m.shape[0] for m, _, _, _ in items)
         max_label = max(n for _, _, _, n in items)
+        # pad with the padding id to the batch maximum (dataset.py:75-81: np.pad per utterance + np.asarray of the list);
+        # written as ONE allocation filled in place - 17.5 MB per batch at 16 x 500 x 546 are copied once instead of twice
         pad = self.padding_id
-        mfccs = [np.pad(m, ((0, max_time - m.shape[0]), (0, 0)), 'constant', constant_values=(pad, pad))
-                 for m, _, _, _ in items]
-        labels = [np.pad(l, (0, max_label - n), 'constant', constant_values=(pad, pad)) for _, l, _, n in items]
-        return np.asarray(mfccs), np.asarray(labels), [s for _, _, s, _ in items], [n for _, _, _, n in items]
+        first_m, first_l = items[0][0], items[0][1]
+        mfccs = np.empty((len(items), max_time) + first_m.shape[1:], dtype=np.result_type(*[m.dtype for m, _, _, _ in items]))
+        labels = np.full((len(items), max_label) + first_l.shape[1:], pad, dtype=np.result_type(*[l.dtype for _, l, _, _ in items]))
+        for i, (m, l, _, n) in enumerate(items):
+            mfccs[i, :m.shape[0]] = m
+            mfccs[i, m.shape[0]:] = pad         # only the tail is filled: no pass over the whole batch
+            labels[i, :n] = l
+        return mfccs, labels, [s for _, _, s, _ in items], [n for _, _, _, n in items]
 
     # ------------------------------------------------------------------ asynchronous input pipeline
     def prefetch(self, depth=2, stage=None):
@@ -119,6 +125,11 @@ class DataSet:
             except BaseException as exc:      # surface loader errors in the consumer
                 put(exc)
 
+        # The loader thread holds the interpreter lock through unpickling and array assembly; with CPython's default
+        # 5 ms switch interval the training thread can wait that long to get it back after the GPU step has finished.
+        import sys
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 2e-4))
         t = threading.Thread(target=worker, name='nasr-prefetch', daemon=True)
         t.start()
         try:
@@ -132,6 +143,7 @@ class DataSet:
         finally:
             quit_.set()
             t.join()
+            sys.setswitchinterval(old_interval)
 
     def get_feature_shape(self):
         return [self.config.batch_size, None, self.config.feature_size]

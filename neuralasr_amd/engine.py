@@ -308,6 +308,24 @@ class Engine:
         self._ck(self.lib.nasr_step_void(self.h, byref(v)))
         return bool(v.value)
 
+    def step_results(self, B, T):
+        """(loss, forward_fault, hypotheses) of the step just enqueued, as soon as its forward pass + CTC are done - the
+        backward pass, the exchange and Adam keep running (include/nasr.h, nasr_get_step_results)."""
+        from ctypes import c_int
+        Tp = self.logit_frames(T)
+        ids = np.zeros((B, Tp), np.int32)
+        lens = np.zeros(B, np.int32)
+        loss, fault = c_float(), c_int()
+        self._ck(self.lib.nasr_get_step_results(self.h, byref(loss), byref(fault), _ip(ids), _ip(lens)))
+        return float(loss.value), bool(fault.value), [ids[b, :lens[b]].tolist() for b in range(B)]
+
+    def settle_step(self, previous=False):
+        """True when the latest (or, previous=True, the one-before-latest) optimiser step was void on every rank."""
+        from ctypes import c_int
+        v = c_int()
+        self._ck(self.lib.nasr_settle_step(self.h, int(bool(previous)), byref(v)))
+        return bool(v.value)
+
     def resident_frames(self):
         n = c_int64()
         self._ck(self.lib.nasr_resident_frames(self.h, byref(n)))

@@ -54,6 +54,10 @@ class HipNetwork(Network):
     beam_width = 100
     device_context = True                    # rebuild include_context's stacking on the GPU (1/(2c+1) of the H2D bytes)
     bucketed_allreduce = True                # one process per GPU: exchange per-layer gradient buckets under the backward pass
+    # train() returns as soon as the step's loss and decode exist (after the forward pass + CTC), while the device runs the
+    # backward pass, the exchange and Adam: the next step is enqueued behind it and the device never waits for the host.
+    # A void step (rare: a persistent-recurrence abort on some rank) is noticed one call later and repeated then.
+    async_step = True
 
     def __init__(self, config, fortraining=False):
         Network.__init__(self)
@@ -79,6 +83,8 @@ class HipNetwork(Network):
         self._reducer = None
         self._staged = {}                       # id(mfccs) -> (ticket, weakref to mfccs): batches stage_batch() sent ahead
         self._staged_lock = threading.Lock()
+        self._pending = None                    # the batch of the last fast-path step, until that step is known not to be void
+        self._begun = None                      # begin_step() without its finish_step() yet
         self.global_step = self.config.start_step
         self.load_checkpoint(self.global_step if fortraining else 1, self.config.model_dir)
         if fortraining and self.coll.rank == 0:
@@ -131,6 +137,7 @@ class HipNetwork(Network):
             self.config.write(dst)
 
     def save_checkpoint(self):
+        self._settle()
         if self.coll.rank != 0:
             return
         m, v, step = self.engine.get_adam_state()
@@ -206,7 +213,34 @@ class HipNetwork(Network):
         return loss, ler, hyps
 
     def train(self, mfccs, labels, seq_len, labels_len):
+        self.begin_step(mfccs, labels, seq_len, labels_len)
+        return self.finish_step()
+
+    def begin_step(self, mfccs, labels, seq_len, labels_len):
+        """First half of train(): everything of the optimisation step is ENQUEUED (upload or commit of the staged batch,
+        forward, CTC, backward, gradient exchange, Adam) and the call returns.  The host is free until finish_step() -
+        train_model loads and stages the next batch there, under the step the device is running (the reference loads the
+        next batch inside the timed step with the device idle, train.py:23-26)."""
         self.global_step += 1
+        n, mine = self._towers()
+        if self.async_step and len(mine) == 1 and self.train_ler_decoder == 'greedy':
+            f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, mine[0])
+            self._begun = ('async', (mfccs, f, l, s, ll, n))
+            self._enqueue_step(mfccs, f, l, s, ll, n)
+        else:
+            self._begun = ('sync', (mfccs, labels, seq_len, labels_len))
+
+    def finish_step(self):
+        """Second half of train(): (loss, mean_ler) of the step begun last - available after its forward pass + CTC; the
+        device may still be in its backward pass when this returns."""
+        kind, batch = self._begun
+        self._begun = None
+        if kind == 'async':
+            return self._finish_async(batch)
+        return self._train_sync(*batch)
+
+    def _train_sync(self, mfccs, labels, seq_len, labels_len):
+        self._settle()
         for attempt in range(3):
             out = self._train_once(mfccs, labels, seq_len, labels_len)
             # a rank whose persistent recurrence gave up voids the step on EVERY rank (the fault word is all-reduced with
@@ -216,6 +250,75 @@ class HipNetwork(Network):
             self.logger.warning('step %d was void (persistent recurrence aborted on some rank): repeating it'
                                 % self.global_step)
         raise RuntimeError('training step %d stayed void after 3 attempts' % self.global_step)
+
+    # ------------------------------------------------------------------ the fast path of train()
+    def _enqueue_step(self, mfccs, f, l, s, ll, n):
+        """Everything of one optimisation step, enqueued without waiting for any of it."""
+        ticket = self._take_staged(mfccs)
+        if ticket is not None:
+            self.engine.commit_batch(ticket)
+        elif not (self._use_device_context() and
+                  self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
+            self.engine.upload_batch(f, s, l, ll)
+        self.engine.compute_grads()
+        if self.coll.world > 1:
+            if self._grad_tensor is None:
+                self._grad_tensor = self.engine.grad_tensor()
+                self._reducer = self.coll.bucketed(self.engine, self._grad_tensor) if self.bucketed_allreduce else None
+            if self._reducer is not None:
+                self._reducer.all_reduce()
+            else:
+                self.coll.all_reduce_sum_(self._grad_tensor)
+        self.engine.apply_adam(1.0 / n)
+
+    def _redo_step(self, batch, why):
+        """A void step's batch again, start to finish (every rank takes this path at the same point of its call sequence:
+        the fault word is all-reduced with the gradients)."""
+        mfccs, f, l, s, ll, n = batch
+        for attempt in range(3):
+            self.logger.warning('%s: repeating its batch' % why)
+            self._enqueue_step(None, f, l, s, ll, n)
+            if not self.engine.settle_step(previous=False):
+                return
+        raise RuntimeError('a training step stayed void after 3 attempts')
+
+    def _settle(self):
+        """Before anything that is not the next fast-path step (validation, checkpoint, decode, the slow path): wait for
+        the last fast-path step and repeat it if it was void."""
+        if self._pending is not None:
+            batch, self._pending = self._pending, None
+            if self.engine.settle_step(previous=False):
+                self._redo_step(batch, 'the last training step was void (persistent recurrence aborted on some rank)')
+
+    def _finish_async(self, batch):
+        mfccs, f, l, s, ll, n = batch
+        loss, fwd_fault, hyps = self.engine.step_results(len(s), f.shape[1])
+        if fwd_fault:
+            # THIS rank's forward recurrence aborted: its loss and decode mean nothing.  The step is void on every rank
+            # (the fault word travels with the gradients); it is repeated below, where every rank notices it.
+            loss, ler = float('nan'), float('nan')
+        else:
+            ler = self.engine.label_error_rate(hyps, l, ll)
+        # the step BEFORE this one has ended by now (stream order): was it void?
+        prev, self._pending = self._pending, batch
+        if prev is not None and self.engine.settle_step(previous=True):
+            self._redo_step(prev, 'step %d was void (persistent recurrence aborted on some rank)' % (self.global_step - 1))
+        if fwd_fault and self.coll.world == 1:
+            # single process: nobody else to keep in step with - settle this one now and report the repeat's values
+            self._pending = None
+            self.engine.settle_step(previous=False)
+            self.logger.warning('step %d was void (persistent recurrence aborted): repeating it' % self.global_step)
+            for attempt in range(3):
+                self._enqueue_step(None, f, l, s, ll, n)
+                loss, again, hyps = self.engine.step_results(len(s), f.shape[1])
+                if not self.engine.settle_step(previous=False) and not again:
+                    ler = self.engine.label_error_rate(hyps, l, ll)
+                    break
+            else:
+                raise RuntimeError('training step %d stayed void after 3 attempts' % self.global_step)
+        if self.coll.world > 1:
+            loss, ler = self.coll.mean_scalars([loss, ler])
+        return np.float32(loss), np.float32(ler)
 
     def _use_device_context(self):
         # rand_shift's roll-and-crop (dataset.py:23-31) leaves real neighbour frames where include_context put its pad
@@ -253,6 +356,7 @@ class HipNetwork(Network):
 
     def discard_staged(self):
         """Give back the slots of batches that were staged but never trained on (the loop ended or raised)."""
+        self._settle()
         with self._staged_lock:
             ents, self._staged = list(self._staged.values()), {}
         for ticket, _ in ents:
@@ -284,6 +388,15 @@ class HipNetwork(Network):
                 if self._reducer is not None:
                     self._reducer.all_reduce()
                     reduced = True
+            # One tower in this process: the optimiser step is enqueued BEFORE the host waits for the loss, so the GPU
+            # does not idle through the host's wake-up (Adam is a no-op on the device if the step turns out void)
+            early_adam = len(mine) == 1 and self.train_ler_decoder != 'beam'
+            if early_adam:
+                if self.coll.world > 1 and not reduced:
+                    if self._grad_tensor is None:
+                        self._grad_tensor = self.engine.grad_tensor()
+                    self.coll.all_reduce_sum_(self._grad_tensor)
+                self.engine.apply_adam(1.0 / n)
             # Everything of this tower that reads the step's results sits inside the void handling: a rank whose
             # persistent recurrence gave up must still reach every collective below (the other ranks are waiting in
             # them); the step is repeated by train()
@@ -306,6 +419,8 @@ class HipNetwork(Network):
         if len(mine) > 1:                       # towers time-sliced on one GPU: host-side sum
             self.engine.set_grads((gsum / n).astype(np.float32))
             self.engine.apply_adam(1.0)
+        elif early_adam:
+            pass                                # already enqueued
         elif self.coll.world > 1:               # one tower per GPU: RCCL all-reduce of the flat buffer
             if not reduced:
                 if self._grad_tensor is None:
@@ -320,15 +435,18 @@ class HipNetwork(Network):
         return np.float32(loss), np.float32(ler)
 
     def validate(self, mfccs, labels, seq_len, labels_len):
+        self._settle()
         loss, ler, _ = self._loss_ler(mfccs, labels, seq_len, labels_len)
         return [np.float32(loss), np.float32(ler)]
 
     def evaluate(self, mfccs, labels, seq_len, labels_len):
+        self._settle()
         loss, ler, hyps = self._loss_ler(mfccs, labels, seq_len, labels_len)
         # SparseTensorValue.values: every utterance's ids concatenated (tfnetwork.py:176-177)
         flat = np.asarray([i for h in hyps for i in h], dtype=np.int64)
         return flat, np.float32(loss), np.float32(ler)
 
     def decode(self, mfccs, seq_len):
+        self._settle()
         hyps = self._decode(mfccs, seq_len, self.decoder)
         return np.asarray([i for h in hyps for i in h], dtype=np.int64)

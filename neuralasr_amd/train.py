@@ -15,13 +15,56 @@ logger = get_logger()
 
 
 def train_model(dataTrain, datavalid, config, prefetch=2):
+    """The loop of train.py:14-47.  With a network that offers begin_step / finish_step / stage_batch (HipNetwork) the
+    next batch is loaded, padded and staged towards the GPU BETWEEN the two halves of a step, i.e. while the device runs
+    that step: one host thread, no idle device.  `prefetch` = 0 keeps the reference's order (load, then train) with
+    synchronous uploads; other networks get a loader thread that runs `prefetch` batches ahead."""
     logger.info('Batch Dimensions: ' + str(dataTrain.get_feature_shape()))
     logger.info('Label Dimensions: ' + str(dataTrain.get_label_shape()))
     network = config.load_network(fortraining=True)
     spent, loss_sum, ler_sum = 0.0, 0.0, 0.0     # train_time_sec is never reset (train.py:20,26,34)
-    stage = getattr(network, 'stage_batch', None)      # HipNetwork: the next batch's H2D copy runs under the current step
+    split = prefetch and all(hasattr(network, a) for a in ('begin_step', 'finish_step', 'stage_batch'))
+
+    def report(loss, mean_ler):
+        nonlocal loss_sum, ler_sum
+        loss_sum += loss
+        ler_sum += mean_ler
+        if network.global_step % config.report_step == 0:
+            network.save_checkpoint()
+            logger.info('Step: %04d' % network.global_step + ', cost = %.4f' % (loss_sum / config.report_step) +
+                        ', ler = %.4f' % (ler_sum / config.report_step) + ', time = %.4f' % spent)
+            loss_sum = ler_sum = 0.0
+            if datavalid:
+                if not datavalid.has_more_batches():
+                    datavalid.reset_epoch()
+                vm, vl, vs, vll = datavalid.get_next_batch()
+                vloss, vler = network.validate(vm, vl, vs, vll)
+                logger.info('Valid: cost = %.4f' % vloss + ', ler = %.4f' % vler)
+
+    if split:
+        def all_batches():                                # epochs x batches, in the reference's order
+            for _ in range(config.epochs):
+                while dataTrain.has_more_batches():
+                    yield dataTrain.get_next_batch()
+                dataTrain.reset_epoch()
+        it = all_batches()
+        t0 = time.time()
+        cur = next(it, None)
+        while cur is not None:
+            network.begin_step(*cur)
+            nxt = next(it, None)                          # loaded, padded and staged under the step the device is running
+            if nxt is not None:
+                network.stage_batch(*nxt)
+            loss, mean_ler = network.finish_step()
+            spent += time.time() - t0
+            report(loss, mean_ler)
+            t0 = time.time()
+            cur = nxt
+        network.discard_staged()
+        logger.info('Finished training!!!')
+        return network
     for _ in range(config.epochs):
-        batches = dataTrain.prefetch(prefetch, stage=stage) if prefetch else iter(dataTrain.get_next_batch, None)
+        batches = dataTrain.prefetch(prefetch) if prefetch else iter(dataTrain.get_next_batch, None)
         while True:
             t0 = time.time()
             if not prefetch and not dataTrain.has_more_batches():
@@ -32,19 +75,7 @@ def train_model(dataTrain, datavalid, config, prefetch=2):
                 break
             loss, mean_ler = network.train(mfccs, labels, seq_len, labels_len)
             spent += time.time() - t0
-            loss_sum += loss
-            ler_sum += mean_ler
-            if network.global_step % config.report_step == 0:
-                network.save_checkpoint()
-                logger.info('Step: %04d' % network.global_step + ', cost = %.4f' % (loss_sum / config.report_step) +
-                            ', ler = %.4f' % (ler_sum / config.report_step) + ', time = %.4f' % spent)
-                loss_sum = ler_sum = 0.0
-                if datavalid:
-                    if not datavalid.has_more_batches():
-                        datavalid.reset_epoch()
-                    vm, vl, vs, vll = datavalid.get_next_batch()
-                    vloss, vler = network.validate(vm, vl, vs, vll)
-                    logger.info('Valid: cost = %.4f' % vloss + ', ler = %.4f' % vler)
+            report(loss, mean_ler)
         dataTrain.reset_epoch()
         if hasattr(network, 'discard_staged'):
             network.discard_staged()

@@ -394,3 +394,61 @@ def test_in_library_rccl_exchange_at_world_one():
     assert a.comm_size() == 1
     a.close()
     b.close()
+
+
+@needs_persistent
+def test_begin_finish_and_async_train_follow_the_synchronous_path(tmp_path):
+    """train() = begin_step() + finish_step(); with async_step the values come back after the forward pass + CTC while the
+    backward pass still runs.  Losses, LERs and parameters are those of the synchronous path (async_step = False), bit for
+    bit, over several steps with a validation in between."""
+    nets = []
+    for k, fast in enumerate((True, False)):
+        cfg = Config(make_config(tmp_path, network='networks.bilstm_ctc_net.BiLstm3x500CTCNet', num_gpus='1', batch_size='4',
+                                 model_dir=str(tmp_path / ('a%d' % k))), True)
+        net = cfg.load_network(fortraining=True)
+        net.async_step = fast
+        nets.append((net, DataSet(cfg.train_input, cfg).get_next_batch()))
+    (a, batch), (b, _) = nets
+    b.engine.set_params(a.engine.get_params())
+    outs = []
+    for step in range(4):
+        if step == 2:
+            a.begin_step(*batch)
+            ra = a.finish_step()
+        else:
+            ra = a.train(*batch)
+        rb = b.train(*batch)
+        assert ra == rb, (step, ra, rb)
+        if step == 2:
+            assert a.validate(*batch) == b.validate(*batch)       # settles the pending step first
+        outs.append(ra)
+    assert a.global_step == b.global_step == 4
+    np.testing.assert_array_equal(a.engine.get_params(), b.engine.get_params())
+    assert a.engine.get_adam_state()[2] == b.engine.get_adam_state()[2] == 4
+
+
+@needs_persistent
+def test_async_train_repeats_a_step_whose_backward_pass_was_void(tmp_path, monkeypatch, caplog):
+    """A persistent-BPTT abort (injected into the backward kernel only) is not known when train() returns - the loss of the
+    forward pass is good, the step is void.  The next call notices it (the previous step's fault word, read without a
+    stream sync) and repeats that batch: after two calls the parameters have had two updates, like an undisturbed run."""
+    import logging
+    cfgs = [Config(make_config(tmp_path, num_gpus='1', model_dir=str(tmp_path / ('v%d' % k))), True) for k in range(2)]
+    net, ref = [c.load_network(fortraining=True) for c in cfgs]
+    ref.engine.set_params(net.engine.get_params())
+    batch = DataSet(cfgs[0].train_input, cfgs[0]).get_next_batch()
+    want = [ref.train(*batch) for _ in range(2)]
+    monkeypatch.setenv('NASR_PERSIST_FAULT', '2')
+    monkeypatch.setenv('NASR_PERSIST_FAULT_KERNEL', 'bwd')
+    got0 = net.train(*batch)
+    monkeypatch.delenv('NASR_PERSIST_FAULT')
+    monkeypatch.delenv('NASR_PERSIST_FAULT_KERNEL')
+    assert float(got0[0]) == pytest.approx(float(want[0][0]), rel=2e-6)       # the forward pass of the void step was fine
+    with caplog.at_level(logging.WARNING):
+        got1 = net.train(*batch)                  # step 2 on the still un-updated parameters, then the repeat of step 1
+    assert any('void' in r.getMessage() for r in caplog.records)
+    assert float(got1[0]) == pytest.approx(float(want[0][0]), rel=2e-5)       # its loss is that of un-updated parameters
+    net.save_checkpoint()                         # settles the last step
+    assert net.engine.recurrence_mode == 'per-step' and net.global_step == 2
+    assert net.engine.get_adam_state()[2] == 2
+    np.testing.assert_allclose(net.engine.get_params(), ref.engine.get_params(), rtol=0, atol=1e-4)
