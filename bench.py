@@ -384,12 +384,17 @@ def main():
     dt_own = time.perf_counter() - t0
     dt = reduce_scalar(dt_own, dist.ReduceOp.MAX) if use_dist else dt_own
     total_frames = reduce_scalar(frames, dist.ReduceOp.SUM) if use_dist else float(frames)
-    loss = eng.get_loss()                 # also surfaces a void step / an aborted persistent launch on this rank
+    # also surfaces a void step / an aborted persistent launch on this rank: reported in the line, never fatal here
+    loss, rank_error = float('nan'), None
+    try:
+        loss = eng.get_loss()
+    except Exception as exc:              # noqa: BLE001
+        rank_error = str(exc)[:200]
     # what every rank ran: a rank that fell back to the per-step kernels (or saw void steps) slows the whole job and
     # would be invisible in rank 0's line otherwise
     aborts, rearms = eng.persist_stats()
     mine = {'rank': rank, 'ms_per_step': dt_own / args.steps * 1e3, 'recurrence': eng.recurrence_mode,
-            'persist_aborts': aborts, 'persist_rearms': rearms, 'frames': int(frames), 'loss': loss}
+            'persist_aborts': aborts, 'persist_rearms': rearms, 'frames': int(frames), 'loss': loss, 'error': rank_error}
     ranks = [mine]
     if use_dist:
         ranks = [None] * world
