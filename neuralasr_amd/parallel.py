@@ -42,6 +42,12 @@ class Collective:
             self.dist = None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
+        # loss / LER means travel as host floats.  Under an NCCL process group they get a gloo group of their own: an
+        # NCCL collective would queue up behind the gradient buckets of the step (one communicator, issue order), i.e.
+        # wait for the END of the backward pass, and NCCL takes no CPU tensors.  (Collective: every rank constructs this.)
+        self.scalar_group = None
+        if self.dist and self.world > 1 and self.dist.get_backend() == 'nccl':
+            self.scalar_group = self.dist.new_group(backend='gloo')
 
     def all_reduce_sum_(self, tensor):
         if self.dist:
@@ -61,7 +67,7 @@ class Collective:
             return [float(v) for v in values]
         import torch
         t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or 'cpu')
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.scalar_group if device is None else None)
         return [float(x) / self.world for x in t.tolist()]
 
 

@@ -103,3 +103,54 @@ def test_two_ranks_on_one_gpu_match_the_global_batch(tmp_path):
     np.testing.assert_allclose(r0['params'], ref.get_params(), rtol=0, atol=5e-5)
     assert (np.abs(r0['params'] - ref.get_params()) > 2e-6).mean() < 2e-3
     ref.close()
+
+
+def _net_worker(rank, world, port, cfg_path, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), NASR_PERSIST='0', LOCAL_RANK='0', RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from neuralasr_amd.config import Config
+    from neuralasr_amd.dataset import DataSet
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        cfg = Config(cfg_path, True)
+        cfg.model_dir = os.path.join(out_dir, 'model')              # rank 0 wipes / writes it
+        net = cfg.load_network(fortraining=True)
+        assert net.coll.world == 2 and net._towers() == (2, [rank])
+        batch = DataSet(cfg.train_input, cfg).get_next_batch()      # every rank sees the GLOBAL batch (train.py)
+        outs = [net.train(*batch) for _ in range(3)]
+        v = net.validate(*batch)
+        np.savez(os.path.join(out_dir, 'n%d.npz' % rank), params=net.engine.get_params(), outs=np.array(outs, np.float64),
+                 valid=np.array(v, np.float64), step=net.engine.get_adam_state()[2])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hipnetwork_train_with_one_process_per_tower(tmp_path):
+    """HipNetwork.train / validate under torch.distributed with one process per tower (two ranks on the one GPU, gloo):
+    the asynchronous step (results after the forward pass, gradient all-reduce + Adam(1/n) enqueued, loss / LER averaged
+    over the ranks) gives the parameters and the values of ONE process time-slicing the same two towers."""
+    import torch.multiprocessing as mp
+    from test_gpu_network import make_config
+    from neuralasr_amd.config import Config
+    from neuralasr_amd.dataset import DataSet
+    cfg_path = make_config(tmp_path, network='networks.lstm_ctc_net.SmallLstmCTCNet')
+    mp.spawn(_net_worker, args=(2, _free_port(), cfg_path, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / 'n0.npz'), np.load(tmp_path / 'n1.npz')
+    np.testing.assert_array_equal(r0['params'], r1['params'])
+    np.testing.assert_array_equal(r0['outs'], r1['outs'])
+    assert int(r0['step']) == int(r1['step']) == 3
+    os.environ['NASR_PERSIST'] = '0'
+    try:
+        cfg = Config(cfg_path, True)
+        cfg.model_dir = str(tmp_path / 'model_ref')
+        ref = cfg.load_network(fortraining=True)                    # num_gpus = 2: both towers in this process
+    finally:
+        del os.environ['NASR_PERSIST']
+    batch = DataSet(cfg.train_input, cfg).get_next_batch()
+    want = np.array([ref.train(*batch) for _ in range(3)], np.float64)
+    np.testing.assert_allclose(r0['outs'], want, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(r0['valid'], np.array(ref.validate(*batch), np.float64), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(r0['params'], ref.engine.get_params(), rtol=0, atol=2e-4)
