@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(
 #pragma unroll
       for (int x = 0; x < CH; ++x) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) av[m][x] = ha[((size_t)m * (Hp >> 4) + qc + x) * 64];
-        bu[x] = ldw(ub + (size_t)(qc + x) * 64);
+        for (int m = 0; m < MT; ++m)
+          if (!(NASR_ABL & 2)) av[m][x] = ha[((size_t)m * (Hp >> 4) + qc + x) * 64];
+        if (!(NASR_ABL & 1)) bu[x] = ldw(ub + (size_t)(qc + x) * 64);
       }
     }
 #pragma unroll

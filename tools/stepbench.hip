@@ -1,5 +1,6 @@
 // stepbench.hip — development microbenchmark: times T graph-captured launches of the per-timestep
 // recurrence kernels with ablations (-DNASR_ABL=mask) to find where a step's time goes.
+// -DSB_H=2048 -DSB_B=32 -DSB_T=100: DeepSpeech's wide layer.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DNASR_ABL=<mask> -I neuralasr_amd/csrc tools/stepbench.hip -o /tmp/sb
 #include "../neuralasr_amd/csrc/lstm.hip"
 #include <cstdio>
@@ -8,7 +9,16 @@
 using namespace nasr;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 int main(int argc, char** argv) {
-  const int T = 500, B = 16, Bp = 16, H = 500, Hp = 512, D = 2, N4 = 4 * Hp;
+#ifndef SB_H
+#define SB_H 500
+#endif
+#ifndef SB_B
+#define SB_B 16
+#endif
+#ifndef SB_T
+#define SB_T 500
+#endif
+  const int T = SB_T, B = SB_B, Bp = (SB_B + 15) / 16 * 16, H = SB_H, Hp = (SB_H + 63) / 64 * 64, D = 2, N4 = 4 * Hp;
   const int mode = argc > 1 ? atoi(argv[1]) : 0;  // 0 fwd, 1 bwd
   const size_t R = (size_t)T * Bp;
   float *Uf, *Ub, *hst, *part, *dcst, *gates, *dgbuf, *cbuf, *out, *dout; int* seq;
