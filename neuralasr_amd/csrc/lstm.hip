@@ -328,8 +328,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
     float* __restrict__ dgbuf,        // [R][D*N4] dG, frame indexed
     const float* __restrict__ cbuf, const float* __restrict__ dout, const float* __restrict__ dcin,
     float* __restrict__ dcout, const int* __restrict__ seq_len, int s, int T, int Bp, int Hp, int D) {
-  __shared__ __attribute__((aligned(16))) float As[MT][128][17];
-  __shared__ __attribute__((aligned(16))) float red[4][MT][4][64][4];
+  // wide form (PRE): the reduction buffer reuses the dG slice's LDS (32 KB instead of 49 KB at MT = 2), so that the four
+  // blocks a CU gets at Hp = 2048 are resident together instead of three and a straggler
+  constexpr int AS_FLOATS = MT * 128 * 17, RED_FLOATS = 4 * MT * 4 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) float lds_[PRE ? (AS_FLOATS > RED_FLOATS ? AS_FLOATS : RED_FLOATS) : AS_FLOATS + RED_FLOATS];
+  float (*As)[128][17] = reinterpret_cast<float (*)[128][17]>(lds_);
+  float (*red)[MT][4][64][4] = reinterpret_cast<float (*)[MT][4][64][4]>(PRE ? lds_ : lds_ + AS_FLOATS);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int KSPLIT = KSP > 0 ? KSP : (Hp >> 5);     // K slices of 32 units in the operand image
   const int NKG = KSPLIT / KSL;                      // K-slice groups = partial sums per output
@@ -461,6 +465,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(
     }
   }
   }   // K-slice loop
+  if (PRE) __syncthreads();                            // every wave's fragment reads of As are done: red overwrites it
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -523,19 +528,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(const float* __restr
 }
 
 // partial sums a BPTT step hands on: Hp/32 of them per output, Hp/128 for the wide-layer form
-int lstm_bwd_partials(int Hp) { return Hp > 512 ? Hp / 128 : Hp / 32; }
+#ifndef NASR_BWD_KSL
+#define NASR_BWD_KSL 4   // K slices a block of the wide form walks (tools/stepbench.hip A/B: 2, 4, 8)
+#endif
+int lstm_bwd_partials(int Hp) { return Hp > 512 ? Hp / (32 * NASR_BWD_KSL) : Hp / 32; }
 
 void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const float* pin, float* pout,
                           const float* gates, float* dgbuf, const float* cbuf, const float* dout, const float* dcin,
                           float* dcout, const int* seq_len, hipStream_t st) {
   const int MT = dm.Bp / 16, ksp = dm.Hp / 32;
   if (dm.Hp > 512 && dm.Hp % 128 == 0) {     // wide layer: cell arithmetic once, then the product (see the kernel's header)
-    const int np = dm.Hp / 128;
+    const int np = dm.Hp / (32 * NASR_BWD_KSL);
     hipLaunchKernelGGL(lstm_bwd_cell_kernel, dim3((dm.Bp * dm.Hp + 255) / 256, dm.D), dim3(256), 0, st, pin, np, gates, dgbuf,
                        cbuf, dout, dcin, dcout, seq_len, s, dm.Bp, dm.Hp, dm.D);
     dim3 gridw((dm.Hp / 64) * np, dm.D);
 #define NASR_BWDW(MTV)                                                                                              \
-  hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV, 0, true, 4>), gridw, dim3(256), 0, st, Ub, pin, pout, gates, dgbuf, cbuf, \
+  hipLaunchKernelGGL((lstm_bwd_step_kernel<MTV, 0, true, NASR_BWD_KSL>), gridw, dim3(256), 0, st, Ub, pin, pout, gates, dgbuf, cbuf, \
                      dout, dcin, dcout, seq_len, s, dm.T, dm.Bp, dm.Hp, dm.D)
     switch (MT) {
       case 1: NASR_BWDW(1); break;
