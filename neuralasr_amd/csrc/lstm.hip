@@ -531,13 +531,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(const float* __restr
 #ifndef NASR_BWD_KSL
 #define NASR_BWD_KSL 4   // K slices a block of the wide form walks (tools/stepbench.hip A/B: 2, 4, 8)
 #endif
-int lstm_bwd_partials(int Hp) { return Hp > 512 ? Hp / (32 * NASR_BWD_KSL) : Hp / 32; }
+static bool bwd_wide_form(int Hp) { return Hp > 512 && Hp % (32 * NASR_BWD_KSL) == 0; }
+int lstm_bwd_partials(int Hp) { return bwd_wide_form(Hp) ? Hp / (32 * NASR_BWD_KSL) : Hp / 32; }
 
 void launch_lstm_bwd_step(const LstmDims& dm, int s, const float* Ub, const float* pin, float* pout,
                           const float* gates, float* dgbuf, const float* cbuf, const float* dout, const float* dcin,
                           float* dcout, const int* seq_len, hipStream_t st) {
   const int MT = dm.Bp / 16, ksp = dm.Hp / 32;
-  if (dm.Hp > 512 && dm.Hp % 128 == 0) {     // wide layer: cell arithmetic once, then the product (see the kernel's header)
+  if (bwd_wide_form(dm.Hp)) {     // wide layer: cell arithmetic once, then the product (see the kernel's header)
     const int np = dm.Hp / (32 * NASR_BWD_KSL);
     hipLaunchKernelGGL(lstm_bwd_cell_kernel, dim3((dm.Bp * dm.Hp + 255) / 256, dm.D), dim3(256), 0, st, pin, np, gates, dgbuf,
                        cbuf, dout, dcin, dcout, seq_len, s, dm.Bp, dm.Hp, dm.D);

@@ -44,6 +44,9 @@ CASES = [
     (O.ModelSpec(12, 20, 2, False, 'none', 40), 33, 10, True),      # three M tiles, C > 32
     (O.ModelSpec(11, 32, 3, False, 'none', 6), 4, 75, True),        # a 3-layer unidirectional stack, T >= 64
     (O.ModelSpec(11, 24, 2, False, 'none', 6), 5, 133, True),       # 4 chunks, ragged last chunk
+    # hidden sizes without a persistent instantiation (Hp > 512): the per-timestep kernels
+    (O.ModelSpec(12, 600, 1, True, 'concat', 6), 40, 8, True),      # Hp 640: two-launch wide BPTT form, three M tiles
+    (O.ModelSpec(12, 530, 1, False, 'none', 6), 3, 9, True),        # Hp 576 (not a multiple of 128): one-launch form, 18 partial sums
 ]
 
 
