@@ -47,6 +47,16 @@ CASES = [
     # hidden sizes without a persistent instantiation (Hp > 512): the per-timestep kernels
     (O.ModelSpec(12, 600, 1, True, 'concat', 6), 40, 8, True),      # Hp 640: two-launch wide BPTT form, three M tiles
     (O.ModelSpec(12, 530, 1, False, 'none', 6), 3, 9, True),        # Hp 576 (not a multiple of 128): one-launch form, 18 partial sums
+    # shape sweep: every padded hidden size class, M-tile count, class count and feature width the kernels branch on
+    (O.ModelSpec(7, 150, 2, True, 'concat', 3), 7, 9, True),        # Hp 192
+    (O.ModelSpec(30, 300, 1, True, 'stack_reshape', 29), 17, 8, True),   # Hp 320, two M tiles
+    (O.ModelSpec(21, 400, 2, False, 'none', 12), 50, 7, True),      # Hp 448, four M tiles
+    (O.ModelSpec(546, 500, 1, True, 'concat', 29), 64, 6, True),    # Hp 512 at the largest per-GPU batch
+    (O.ModelSpec(5, 700, 1, True, 'concat', 4), 2, 7, False),       # Hp 704: per-step kernels, 22 partial sums
+    (O.ModelSpec(9, 1000, 2, False, 'none', 8), 20, 6, True),       # Hp 1024: wide BPTT form, two M tiles, two layers
+    (O.ModelSpec(1, 8, 1, True, 'concat', 3), 1, 5, False),         # one feature, two label classes + blank
+    (O.ModelSpec(1100, 33, 1, False, 'none', 70), 9, 11, True),     # features wider than a GEMM K panel, C > 64
+    (O.ModelSpec(14, 48, 4, True, 'concat', 150), 5, 14, True),     # four layers, C > 128
 ]
 
 
