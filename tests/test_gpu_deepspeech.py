@@ -36,6 +36,9 @@ CASES = [
     # dropout and clip: several GEMM tiles per stage, split-K weight gradients, the persistent recurrence at Hp 256
     (O.ModelSpec(546, 256, 1, True, 'concat', 29, pre=(256, 256, 512), post=256, relu_clip=20.0,
                  dropout=(0.05, 0.05, 0.05, 0.05)), 8, 60),
+    # odd stage widths around a recurrence wider than the persistent kernels take (Hp 640: per-step kernels, wide BPTT
+    # form), three M tiles
+    (O.ModelSpec(20, 600, 1, True, 'concat', 7, pre=(70, 130), post=50, relu_clip=2.0, dropout=(0.1, 0.0, 0.2)), 33, 9),
 ]
 
 
