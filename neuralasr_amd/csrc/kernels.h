@@ -127,6 +127,31 @@ void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* 
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
                              float* fault, hipStream_t st, bool ctl_zeroed = false);
 
+// ---- wide persistent forward recurrence (lstm_wide.hip): Hp = 2048, one launch per direction over all 256 CUs ----
+struct WideCtl {               // device words, zeroed before every launch
+  unsigned xcc_count[8];
+  unsigned error;              // bit 0: a bounded spin gave up, bit 1: placement is not 32 workgroups on each of 8 XCDs
+  unsigned pad[23];
+  unsigned hflag[8 * 32];      // [XCD x][member]: timesteps whose h this workgroup has published
+  unsigned pflag[256 * 32];    // [destination workgroup][source XCD] (8 of 32 words used: one 128-byte line per inbox)
+};
+struct WideGeom {
+  int T, Bp, Hp, D, d;
+  int inject;                  // test hook (NASR_WIDE_FAULT=s): workgroup (0,0) treats the poll of step s as timed out
+  float* fault;
+};
+bool wide_supported(int Hp, int Bp);
+size_t wide_image_bytes(int Hp);     // one direction's operand image
+size_t wide_hx_bytes(int Bp);        // h exchange buffer
+size_t wide_part_bytes(int Bp);      // partial-sum exchange buffer
+hipError_t wide_prepare();           // once per process: raise the kernels' dynamic-LDS limit
+// U [Hp][4Hp] canonical, cs [4Hp] power-of-two column scales -> Uw (wide_image_bytes)
+void launch_repack_wide(const float* U, const float* cs, void* Uw, int Hp, hipStream_t st);
+// direction d of one layer: Uw / cinv ([4Hp], 1 / cs) of that direction; gates/cbuf/out frame-indexed as everywhere
+void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float* cinv, float* gates, float* cbuf,
+                          float* out, const int* seq_len, void* hx, float* part, WideCtl* ctl, unsigned* sticky,
+                          float* fault, float forget_bias, hipStream_t st);
+
 // ---- DeepSpeech dense stages (dense.hip): clipped ReLU + hash-defined dropout, in place ----
 void launch_dense_act(float* z, int R, int Bp, int B, int W, int ld, float clip, float p, uint32_t seed, uint32_t counter,
                       int stage, hipStream_t st);

@@ -1,0 +1,380 @@
+// lstm_wide.hip — the forward recurrence of a WIDE layer (Hp = 2048, DeepSpeech's cell count: networks/deepspeech.py:70-103)
+// as one persistent launch per direction.
+//
+// Same semantics and buffers as lstm.hip / lstm_persist.hip.  Why a third form: the
+// persistent kernels of lstm_persist.hip keep a direction's recurrent matrix in the registers of ONE XCD (Hp <= 512);
+// at Hp = 2048 a direction's U is 64 MB — half the chip's register files — and the per-timestep launches of lstm.hip
+// re-stream it through the fabric every step (30 us per step, fp32 MFMA floor 13.7 us besides).  Here:
+//
+//   * ONE direction per launch, its U resident in the registers of all 256 CUs: 256 KB per CU = 8 waves x 128 VGPRs,
+//     as two fp16 planes under per-column power-of-two scales (the form of lstm_persist.hip's forward kernel).
+//   * the CUs form a 2-D grid.  XCD x owns the CONTRACTION rows of hidden units [KS*x, KS*x + KS) (KS = Hp/8 = 256);
+//     member nb of every XCD owns the gate columns of units {KS*x' + 8*nb + i : x' < 8, i < 8}: 8 units from each row
+//     slice.  Wave w of a workgroup holds the columns that belong to slice x' = w.
+//   * per timestep two hand-offs: (1) h_{s-1} of the XCD's own row slice through the XCD's L2 (32 producers x 1 KB,
+//     plain stores + sc1 loads, as lstm_persist.hip); (2) the 8 partial sums of every unit cross the XCDs: wave w
+//     sends its 16*MT x 32 partial pre-activations to workgroup (w, nb) (sc1 write-through stores + flag), which sums
+//     the 8 in fixed order, does the cell update of its 8 units (c in a register for all T) and publishes h.
+//   * products on v_mfma_f32_16x16x32_f16: h*2^14 split into two fp16 parts by its producer, three products per tile.
+//
+// Placement is read from HW_REG_XCC_ID with a ticket per XCD; every spin is bounded; a timeout or an unexpected placement
+// raises WideCtl::error (+ the sticky host word and the fault float) and the launch drains.
+#include "kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace nasr {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ float wexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float wsig(float x) { return __builtin_amdgcn_rcpf(1.f + wexp(-x)); }
+__device__ __forceinline__ float wtanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + wexp(2.f * x)); }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void wstatic_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    wstatic_for<I + 1, N>(f);
+  }
+}
+
+constexpr unsigned WIDE_SPIN = 1u << 21;
+
+__device__ __forceinline__ bool wpoll_ge(gu32* p, bool active, unsigned want) {
+  for (unsigned n = 0; n < WIDE_SPIN; ++n) {
+    const unsigned v = active ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+    if (__all((int)(v - want) >= 0)) return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ u32x4 ld16_sc1(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// (the compiler's hazard recogniser does not look inside inline asm: a VALU write of the data registers in the slot right
+//  behind a store of more than 8 bytes corrupts the tail of the store, hence the s_nop)
+__device__ __forceinline__ void st16_sc1(void* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+// wait for the asm loads above; the loaded value passes through the statement so that no copy of it is scheduled earlier
+__device__ __forceinline__ void wait_vm0(u32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); }
+
+__device__ __forceinline__ void wide_raise(WideCtl* ctl, unsigned* sticky, float* fault, unsigned code) {
+  atomicOr(&ctl->error, code);
+  if (fault) *fault = 1.f;
+  if (sticky) __hip_atomic_store(sticky, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ operand image
+// U canonical [Hp][N4] (row k = h unit, column 4*j + g), cs [N4] power-of-two column scales.
+// Uw as 16-byte units [8 x][32 nb][8 w][8 kt][2 h2][2 plane][64 lane]: lane l holds the 8 halfs
+//   U[k = KS*x + 32*kt + 8*(l>>4) + 0..7][col = 4*(KS*w + 8*nb + 4*h2 + ((l&15)>>2)) + (l&3)] * cs[col],
+//   plane 0 = fp16(v), plane 1 = fp16(v - plane 0): the B operand of v_mfma_f32_16x16x32_f16.
+__global__ __launch_bounds__(256) void repack_wide_kernel(const float* __restrict__ U, const float* __restrict__ cs,
+                                                          u32x4* __restrict__ Uw, int Hp) {
+  const int KS = Hp / 8, N4 = 4 * Hp;
+  const int64_t total = (int64_t)8 * 32 * 8 * 8 * 2 * 64;   // (x, nb, w, kt, h2, lane)
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(e & 63);
+    int64_t r = e >> 6;
+    const int h2 = (int)(r & 1); r >>= 1;
+    const int kt = (int)(r & 7); r >>= 3;
+    const int w = (int)(r & 7); r >>= 3;
+    const int nb = (int)(r & 31), x = (int)(r >> 5);
+    const int col = 4 * (KS * w + 8 * nb + 4 * h2 + ((l & 15) >> 2)) + (l & 3);
+    const int k0 = KS * x + 32 * kt + 8 * (l >> 4);
+    const float sc = cs[col];
+    h8 p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = U[(size_t)(k0 + j) * N4 + col] * sc;
+      const _Float16 a = (_Float16)v;
+      p1[j] = a;
+      p2[j] = (_Float16)(v - (float)a);
+    }
+    u32x4* dst = Uw + (e >> 6) * 128 + l;
+    dst[0] = __builtin_bit_cast(u32x4, p1);
+    dst[64] = __builtin_bit_cast(u32x4, p2);
+  }
+}
+
+size_t wide_image_bytes(int Hp) { return (size_t)Hp * 4 * Hp * 4; }
+bool wide_supported(int Hp, int Bp) { return Hp == 2048 && Bp >= 16 && Bp <= 64 && Bp % 16 == 0; }
+size_t wide_hx_bytes(int Bp) { return (size_t)2 * 8 * 32 * 2 * Bp * 16; }
+size_t wide_part_bytes(int Bp) { return (size_t)2 * 256 * 8 * (Bp / 16) * 2 * 64 * 16; }
+
+void launch_repack_wide(const float* U, const float* cs, void* Uw, int Hp, hipStream_t st) {
+  hipLaunchKernelGGL(repack_wide_kernel, dim3(2048), dim3(256), 0, st, U, cs, reinterpret_cast<u32x4*>(Uw), Hp);
+}
+
+// ------------------------------------------------------------------ forward
+// LDS map (16-byte units): A [8 kt][MT][2 p][64] | P [8 src][MT][2 h2][64] | hp [2 p][16*MT rows] | info
+template <int MT>
+struct WideLds {
+  static constexpr int A = 0, P = A + 8 * MT * 2 * 64, HP = P + 8 * MT * 2 * 64, INFO = HP + 2 * 16 * MT, END = INFO + 4;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
+    const u32x4* __restrict__ Uw,       // this direction's image
+    float* gates, float* cbuf, float* out, const int* __restrict__ seq_len,
+    u32x4* hx,                           // [2 parity][8 x][32 nb][2 plane][16*MT rows]: 8 halfs of h*2^14 per unit
+    float* part,                         // [2 parity][256 dest][8 src][MT][2 h2][64 lane][4]
+    WideCtl* ctl, unsigned* sticky, WideGeom gm, float fb, const float* __restrict__ cinv) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 wlds[];
+  using L = WideLds<MT>;
+  constexpr int ROWS = 16 * MT;
+  u32x4* Alds = wlds + L::A;
+  f32x4* Plds = reinterpret_cast<f32x4*>(wlds + L::P);
+  _Float16* hp = reinterpret_cast<_Float16*>(wlds + L::HP);
+  unsigned* info = reinterpret_cast<unsigned*>(wlds + L::INFO);
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+
+  // ---- placement: XCD id = row slice x, ticket = member nb
+  if (tid == 0) {
+    const unsigned xi = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+    info[0] = xi;
+    info[1] = xi < 8 ? atomicAdd(&ctl->xcc_count[xi], 1u) : 0xffffu;
+    info[2] = 0;
+    info[3] = 0;
+  }
+  __syncthreads();
+  const int x = (int)info[0], nb = (int)info[1];
+  if (x >= 8 || nb >= 32) {
+    if (tid == 0) wide_raise(ctl, sticky, gm.fault, 2u);
+    return;
+  }
+  const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D, d = gm.d;
+  const int KS = Hp / 8, N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
+  const int me = x * 32 + nb;
+
+  // ---- this wave's 256 x 32 block of U (destination slice w), resident for the whole launch: 128 VGPRs
+  h8 ur[8][2][2];
+  {
+    const u32x4* up = Uw + ((size_t)(me * 8 + w) * 8) * 4 * 64 + lane;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ur[kt][h2][p] = __builtin_bit_cast(h8, up[((kt * 2 + h2) * 2 + p) * 64]);
+  }
+  float osc[2];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2)
+    osc[h2] = cinv[4 * (KS * w + 8 * nb + 4 * h2 + ((lane & 15) >> 2)) + (lane & 3)] * (1.f / 16384.f);
+
+  gu32* hflag = (gu32*)(ctl->hflag + x * 32);
+  gu32* pflag_in = (gu32*)(ctl->pflag + me * 32);            // words [src] of this workgroup's inbox
+  gu32* pflag_out = (gu32*)(ctl->pflag + (w * 32 + nb) * 32 + x);
+
+  // ---- cell threads: tid < 128*MT: (row b, unit i of this workgroup's 8)
+  const bool cell = tid < 8 * ROWS;
+  const int cb = tid >> 3, ci = tid & 7;
+  const int u = KS * x + 8 * nb + ci;
+  const int len = (cell && cb < Bp) ? seq_len[cb] : 0;
+  const bool rowok = cell && cb < Bp;
+  float c = 0.f;
+  const unsigned xstep = (unsigned)Bp * (unsigned)DN;
+  const unsigned xoff = (unsigned)(rowok ? cb : 0) * (unsigned)DN + (unsigned)(d * N4 + 4 * u);
+  auto frame_of = [&](int s) { return (rowok && s < len) ? (d ? len - 1 - s : s) : 0; };
+  bool aborted = false;
+
+  for (int s = 0; s < T; ++s) {
+    const int par = s & 1;
+    bool ok = true;
+    // gate pre-activations of this step's frame (x W + b, from the hoisted GEMM): in flight during the whole product phase
+    f32x4 xg = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (cell) xg = *reinterpret_cast<const f32x4*>(gates + (xoff + (unsigned)frame_of(s) * xstep));
+
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (s > 0) {
+      // 1. h_{s-1} of this XCD's row slice: wave w fetches k-tile w = the 8 units of producers 4w .. 4w+3
+      ok = wpoll_ge(hflag + 4 * w + (lane & 3), lane < 4, (unsigned)s) && !(s == gm.inject && me == 0);
+      if (ok) {
+        const u32x4* src = hx + ((size_t)(((s - 1) & 1) * 8 + x) * 32 + 4 * w + (lane >> 4)) * 2 * ROWS + (lane & 15);
+        u32x4 v[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) v[m][p] = ld16_sc1(src + p * ROWS + 16 * m);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) wait_vm0(v[m][p]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) Alds[((w * MT + m) * 2 + p) * 64 + lane] = v[m][p];
+      } else {
+        info[2] = 1;
+      }
+    }
+    __syncthreads();                                        // #1: the A operand is in LDS
+    if (s > 0 && !info[2]) {
+      // 2. partial pre-activations of destination slice w over this XCD's 256 contraction rows
+      wstatic_for<0, 8>([&](auto ktc) {
+        constexpr int kt = decltype(ktc)::value;
+        h8 a[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) a[m][p] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + p) * 64 + lane]);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[m][h2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][1], ur[kt][h2][0], acc[m][h2], 0, 0, 0);
+            acc[m][h2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][0], ur[kt][h2][1], acc[m][h2], 0, 0, 0);
+            acc[m][h2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][0], ur[kt][h2][0], acc[m][h2], 0, 0, 0);
+          }
+      });
+      // 3. hand the partial sums to workgroup (w, nb); the own slice stays in LDS
+      if (w != x) {
+        float* dst = part + ((((size_t)par * 256 + (w * 32 + nb)) * 8 + x) * MT * 2) * 256 + lane * 4;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) st16_sc1(dst + (m * 2 + h2) * 256, acc[m][h2] * osc[h2]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store((unsigned*)pflag_out, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) Plds[((x * MT + m) * 2 + h2) * 64 + lane] = acc[m][h2] * osc[h2];
+      }
+      // 4. the 7 partial sums of the own units that other XCDs computed: wave w fetches source slice w
+      if (w != x) {
+        ok = wpoll_ge(pflag_in + w, lane == 0, (unsigned)s + 1u);
+        if (ok) {
+          const float* src = part + ((((size_t)par * 256 + me) * 8 + w) * MT * 2) * 256 + lane * 4;
+          u32x4 v[MT][2];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) v[m][h2] = ld16_sc1(src + (m * 2 + h2) * 256);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) wait_vm0(v[m][h2]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) Plds[((w * MT + m) * 2 + h2) * 64 + lane] = __builtin_bit_cast(f32x4, v[m][h2]);
+        } else {
+          info[2] = 1;
+        }
+      }
+    }
+    __syncthreads();                                        // #2: the 8 partial sums are in LDS
+    const unsigned abort_word = info[2];
+    // 5. cell update of (row cb, unit ci): sum of the 8 sources in fixed order
+    if (cell) {
+      const bool valid = rowok && s < len;
+      f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (s > 0) {
+        const float* pl = reinterpret_cast<const float*>(Plds) +
+                          (((cb >> 4) * 2 + (ci >> 2)) * 64 + 16 * ((cb & 15) >> 2) + 4 * (ci & 3)) * 4 + (cb & 3);
+#pragma unroll
+        for (int sx = 0; sx < 8; ++sx) {
+          const float* ps = pl + sx * MT * 2 * 256;
+          g.x += ps[0]; g.y += ps[4]; g.z += ps[8]; g.w += ps[12];
+        }
+      }
+      const f32x4 pre = xg + g;
+      f32x4 act;
+      act.x = wsig(pre.x);
+      act.y = wtanh(pre.y);
+      act.z = wsig(pre.z + fb);
+      act.w = wsig(pre.w);
+      float h = 0.f;
+      if (valid) {
+        c = c * act.z + act.x * act.y;
+        h = wtanh(c) * act.w;
+      }
+      const float hv = h * 16384.f;
+      const _Float16 h1 = (_Float16)hv;
+      const _Float16 h2v = (_Float16)(hv - (float)h1);
+      hp[(0 * ROWS + cb) * 8 + ci] = h1;
+      hp[(1 * ROWS + cb) * 8 + ci] = h2v;
+      __builtin_amdgcn_wave_barrier();
+      // the row's 8 halfs were written by 8 consecutive lanes of this wave: LDS operations of one wave complete in order
+      if (ci == 0) {
+        u32x4* dst = hx + ((size_t)(par * 8 + x) * 32 + nb) * 2 * ROWS + cb;
+        dst[0] = *reinterpret_cast<const u32x4*>(hp + (0 * ROWS + cb) * 8);     // plain stores: land in this XCD's L2
+        dst[ROWS] = *reinterpret_cast<const u32x4*>(hp + (1 * ROWS + cb) * 8);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // acknowledged before the flag goes out
+      // per-frame results for the BPTT / the layer above
+      if (rowok) {
+        if (valid) {
+          const unsigned r = (unsigned)((d ? (len - 1 - s) : s) * Bp + cb);
+          *reinterpret_cast<f32x4*>(gates + (r * (unsigned)DN + (unsigned)(d * N4 + 4 * u))) = act;
+          const unsigned oc = r * (unsigned)DH + (unsigned)(d * Hp + u);
+          cbuf[oc] = c;
+          out[oc] = h;
+        } else {
+          out[(unsigned)(s * Bp + cb) * (unsigned)DH + (unsigned)(d * Hp + u)] = 0.f;   // frame s is past seq_len in both directions
+        }
+      }
+    }
+    __syncthreads();                                        // #3: every cell wave's h is acknowledged
+    if (tid == 0) hflag[nb] = (unsigned)s + 1u;
+    if (abort_word) { aborted = true; break; }
+  }
+  if (aborted && tid == 0) wide_raise(ctl, sticky, gm.fault, 1u);
+}
+
+hipError_t wide_prepare() {
+  hipError_t e = hipSuccess;
+#define NASR_WIDE_ATTR(MTV)                                                                                         \
+  if (e == hipSuccess)                                                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wide_fwd_kernel<MTV>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, WideLds<MTV>::END * 16)
+  NASR_WIDE_ATTR(1);
+  NASR_WIDE_ATTR(2);
+  NASR_WIDE_ATTR(3);
+  NASR_WIDE_ATTR(4);
+#undef NASR_WIDE_ATTR
+  return e;
+}
+
+void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float* cinv, float* gates, float* cbuf,
+                          float* out, const int* seq_len, void* hx, float* part, WideCtl* ctl, unsigned* sticky,
+                          float* fault, float forget_bias, hipStream_t st) {
+  (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
+  WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, fault};
+  if (const char* e = getenv("NASR_WIDE_FAULT")) gm.inject = atoi(e);
+  const int MT = dm.Bp / 16;
+#define NASR_WIDE(MTV)                                                                                               \
+  hipLaunchKernelGGL((lstm_wide_fwd_kernel<MTV>), dim3(256), dim3(512), WideLds<MTV>::END * 16, st,                  \
+                     reinterpret_cast<const u32x4*>(Uw), gates, cbuf, out, seq_len, reinterpret_cast<u32x4*>(hx), part, \
+                     ctl, sticky, gm, forget_bias, cinv)
+  switch (MT) {
+    case 1: NASR_WIDE(1); break;
+    case 2: NASR_WIDE(2); break;
+    case 3: NASR_WIDE(3); break;
+    default: NASR_WIDE(4); break;
+  }
+#undef NASR_WIDE
+}
+
+}  // namespace nasr
