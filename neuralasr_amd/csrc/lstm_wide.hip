@@ -25,6 +25,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef NASR_WSTAMP
+#define NASR_WSTAMP 0   // 1: s_memtime deltas per phase, waves of workgroup (0,0) -> WideCtl::pflag tail (tools/widebench)
+#endif
+
 namespace nasr {
 
 namespace {
@@ -177,8 +181,6 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
     osc[h2] = cinv[4 * (KS * w + 8 * nb + 4 * h2 + ((lane & 15) >> 2)) + (lane & 3)] * (1.f / 16384.f);
 
   gu32* hflag = (gu32*)(ctl->hflag + x * 32);
-  gu32* pflag_in = (gu32*)(ctl->pflag + me * 32);            // words [src] of this workgroup's inbox
-  gu32* pflag_out = (gu32*)(ctl->pflag + (w * 32 + nb) * 32 + x);
 
   // ---- cell threads: tid < 128*MT: (row b, unit i of this workgroup's 8)
   const bool cell = tid < 8 * ROWS;
@@ -191,23 +193,26 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
   const unsigned xoff = (unsigned)(rowok ? cb : 0) * (unsigned)DN + (unsigned)(d * N4 + 4 * u);
   auto frame_of = [&](int s) { return (rowok && s < len) ? (d ? len - 1 - s : s) : 0; };
   bool aborted = false;
+#if NASR_WSTAMP
+  unsigned long long tl = __builtin_amdgcn_s_memtime();
+  unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WMARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += (unsigned)(t_ - tl); tl = t_; } while (0)
+#else
+#define WMARK(i) do { } while (0)
+#endif
 
   for (int s = 0; s < T; ++s) {
     const int par = s & 1;
     bool ok = true;
+    WMARK(0);
     // gate pre-activations of this step's frame (x W + b, from the hoisted GEMM): in flight during the whole product phase
     f32x4 xg = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (cell) xg = *reinterpret_cast<const f32x4*>(gates + (xoff + (unsigned)frame_of(s) * xstep));
 
-    f32x4 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
     if (s > 0) {
       // 1. h_{s-1} of this XCD's row slice: wave w fetches k-tile w = the 8 units of producers 4w .. 4w+3
       ok = wpoll_ge(hflag + 4 * w + (lane & 3), lane < 4, (unsigned)s) && !(s == gm.inject && me == 0);
+      WMARK(1);
       if (ok) {
         const u32x4* src = hx + ((size_t)(((s - 1) & 1) * 8 + x) * 32 + 4 * w + (lane >> 4)) * 2 * ROWS + (lane & 15);
         u32x4 v[MT][2];
@@ -227,64 +232,99 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
         info[2] = 1;
       }
     }
+    WMARK(2);
     __syncthreads();                                        // #1: the A operand is in LDS
+    WMARK(3);
     if (s > 0 && !info[2]) {
-      // 2. partial pre-activations of destination slice w over this XCD's 256 contraction rows
-      wstatic_for<0, 8>([&](auto ktc) {
-        constexpr int kt = decltype(ktc)::value;
-        h8 a[MT][2];
+      // 2. + 3. partial pre-activations of destination slice w over this XCD's 256 contraction rows, one 16 x 16 tile
+      // at a time; each tile leaves for workgroup (w, nb) as soon as it is complete (its write-through acknowledgement
+      // overlaps the MFMAs of the next tile); the own slice stays in LDS
+      float* pdst = part + ((((size_t)par * 256 + (w * 32 + nb)) * 8 + x) * MT * 2) * 256 + lane * 4;
+      // (the sentinel stores this wave made as a CONSUMER one step ago are acknowledged: whoever sees the partial sums
+      //  below and later overwrites a slot this wave reset finds the reset already in memory)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WMARK(5);
+      wstatic_for<0, MT>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        // the 16 rows' A fragments of all 8 k-tiles, both planes, in one burst of LDS reads (shared by the two tiles)
+        // (three and four M tiles leave no registers for the burst: there the fragments are read per k-tile)
+        constexpr bool BURST = MT <= 2;
+        h8 a0[BURST ? 8 : 1], a1[BURST ? 8 : 1];
+        if constexpr (BURST) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) a[m][p] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + p) * 64 + lane]);
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            acc[m][h2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][1], ur[kt][h2][0], acc[m][h2], 0, 0, 0);
-            acc[m][h2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][0], ur[kt][h2][1], acc[m][h2], 0, 0, 0);
-            acc[m][h2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][0], ur[kt][h2][0], acc[m][h2], 0, 0, 0);
+          for (int kt = 0; kt < 8; ++kt) {
+            a0[kt] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 0) * 64 + lane]);
+            a1[kt] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 1) * 64 + lane]);
           }
+        }
+        wstatic_for<0, 2>([&](auto hc) {
+          constexpr int h2 = decltype(hc)::value;
+          f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+          wstatic_for<0, 8>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            constexpr int ki = BURST ? kt : 0;
+            if constexpr (!BURST) {
+              a0[0] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 0) * 64 + lane]);
+              a1[0] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 1) * 64 + lane]);
+            }
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ki], ur[kt][h2][0], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ki], ur[kt][h2][1], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ki], ur[kt][h2][0], t, 0, 0, 0);
+          });
+          t *= osc[h2];
+          if (w != x) st16_sc1(pdst + (m * 2 + h2) * 256, t);
+          else Plds[((x * MT + m) * 2 + h2) * 64 + lane] = t;
+        });
       });
-      // 3. hand the partial sums to workgroup (w, nb); the own slice stays in LDS
+      WMARK(4);
+      // 4. the 7 partial sums of the own units that other XCDs computed: wave w fetches source slice w.  No flag: the
+      // inbox holds a sentinel (all ones, a NaN no arithmetic produces) until the data land; the words are polled
+      // themselves, then reset for the step after next (this parity's next use).
       if (w != x) {
-        float* dst = part + ((((size_t)par * 256 + (w * 32 + nb)) * 8 + x) * MT * 2) * 256 + lane * 4;
+        float* src = part + ((((size_t)par * 256 + me) * 8 + w) * MT * 2) * 256 + lane * 4;
+        u32x4 v[MT][2];
+        ok = false;
+        for (unsigned n = 0; n < WIDE_SPIN; ++n) {
+          // the tile stored last first: when it is there the others mostly are
+          v[MT - 1][1] = ld16_sc1(src + ((MT - 1) * 2 + 1) * 256);
+          wait_vm0(v[MT - 1][1]);
+          const u32x4 q = v[MT - 1][1];
+          if (!__all(q.x != 0xffffffffu && q.y != 0xffffffffu && q.z != 0xffffffffu && q.w != 0xffffffffu)) continue;
+          bool all = true;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) st16_sc1(dst + (m * 2 + h2) * 256, acc[m][h2] * osc[h2]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store((unsigned*)pflag_out, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
+            for (int h2 = 0; h2 < 2; ++h2)
+              if (m != MT - 1 || h2 != 1) v[m][h2] = ld16_sc1(src + (m * 2 + h2) * 256);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) Plds[((x * MT + m) * 2 + h2) * 64 + lane] = acc[m][h2] * osc[h2];
-      }
-      // 4. the 7 partial sums of the own units that other XCDs computed: wave w fetches source slice w
-      if (w != x) {
-        ok = wpoll_ge(pflag_in + w, lane == 0, (unsigned)s + 1u);
+            for (int h2 = 0; h2 < 2; ++h2)
+              if (m != MT - 1 || h2 != 1) {
+                wait_vm0(v[m][h2]);
+                const u32x4 t = v[m][h2];
+                all = all && t.x != 0xffffffffu && t.y != 0xffffffffu && t.z != 0xffffffffu && t.w != 0xffffffffu;
+              }
+          if (__all(all)) { ok = true; break; }
+        }
+        WMARK(6);
         if (ok) {
-          const float* src = part + ((((size_t)par * 256 + me) * 8 + w) * MT * 2) * 256 + lane * 4;
-          u32x4 v[MT][2];
+          const f32x4 sent = __builtin_bit_cast(f32x4, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) v[m][h2] = ld16_sc1(src + (m * 2 + h2) * 256);
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) wait_vm0(v[m][h2]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) Plds[((w * MT + m) * 2 + h2) * 64 + lane] = __builtin_bit_cast(f32x4, v[m][h2]);
+            for (int h2 = 0; h2 < 2; ++h2) {
+              Plds[((w * MT + m) * 2 + h2) * 64 + lane] = __builtin_bit_cast(f32x4, v[m][h2]);
+              st16_sc1(src + (m * 2 + h2) * 256, sent);
+            }
         } else {
           info[2] = 1;
         }
       }
     }
+    WMARK(7);
     __syncthreads();                                        // #2: the 8 partial sums are in LDS
+    WMARK(8);
     const unsigned abort_word = info[2];
     // 5. cell update of (row cb, unit ci): sum of the 8 sources in fixed order
     if (cell) {
@@ -337,9 +377,15 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
       }
     }
     __syncthreads();                                        // #3: every cell wave's h is acknowledged
+    WMARK(9);
     if (tid == 0) hflag[nb] = (unsigned)s + 1u;
     if (abort_word) { aborted = true; break; }
   }
+#if NASR_WSTAMP
+  if (lane == 0 && (me == 0 || me == 255))
+    for (int i = 0; i < 10; ++i) ctl->pflag[256 * 32 - 256 + ((me ? 8 : 0) + w) * 10 + i] = tacc[i];
+#endif
+#undef WMARK
   if (aborted && tid == 0) wide_raise(ctl, sticky, gm.fault, 1u);
 }
 
@@ -361,6 +407,7 @@ void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float
                           float* out, const int* seq_len, void* hx, float* part, WideCtl* ctl, unsigned* sticky,
                           float* fault, float forget_bias, hipStream_t st) {
   (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
+  (void)hipMemsetAsync(part, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
   WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, fault};
   if (const char* e = getenv("NASR_WIDE_FAULT")) gm.inject = atoi(e);
   const int MT = dm.Bp / 16;

@@ -130,6 +130,14 @@ struct nasr_ctx {
   size_t imf = 0, imb = 0;             // floats per (layer, direction) image
   float* xch = nullptr;                // exchange buffer
   PersistCtl* pctl = nullptr;
+  // Wide persistent FORWARD recurrence (lstm_wide.hip): Hp = 2048 (DeepSpeech's cell count), one launch per direction
+  // with U resident in the registers of all 256 CUs; the BPTT of such a layer stays on the per-step kernels.  NASR_WIDE=0
+  // (or NASR_PERSIST=0) keeps the per-step forward kernels.  Shares the abort / re-arm bookkeeping above.
+  bool wide = false, wide_wanted = false;
+  unsigned char* Uw = nullptr;         // [L][D] operand images (wide_image_bytes each)
+  void* whx = nullptr;                 // h exchange
+  float* wpart = nullptr;              // partial-sum exchange
+  WideCtl* wctl = nullptr;
   unsigned* perr = nullptr;            // host-mapped sticky error word
   std::string err;
   // in-library gradient exchange (nasr_comm_*): one RCCL rank per handle, collectives on a side stream
@@ -304,6 +312,7 @@ int persist_check(nasr_ctx* h) {
   *reinterpret_cast<volatile unsigned*>(h->perr) = 0;
   h->persist = false;
   h->persist_ok = false;
+  h->wide = false;
   h->persist_aborts += 1;
   h->clean_steps = 0;
   h->rearm_wait = h->persist_aborts <= 1 ? h->rearm_after : std::min<int64_t>(h->rearm_wait * 2, (int64_t)1 << 20);
@@ -346,6 +355,17 @@ bool persist_census(nasr_ctx* h) {
 // After `rearm_wait` clean steps on the per-step kernels: run the census again and go back to the persistent kernels
 // (called at the start of a step, before anything of it is enqueued).
 void persist_rearm(nasr_ctx* h) {
+  if (h->wide_wanted && !h->wide && h->persist_aborts > 0 && h->rearm_wait > 0) {
+    // the wide forward kernel has no census launch of its own: its next launch is the census (a second abort voids that
+    // step, which the caller repeats on the per-step kernels, and doubles the wait)
+    if (++h->clean_steps <= h->rearm_wait) return;
+    h->clean_steps = 0;
+    if (hipStreamSynchronize(h->st) != hipSuccess) return;
+    h->wide = true;
+    if (repack(h) != NASR_OK) { h->wide = false; return; }
+    h->persist_rearms += 1;
+    return;
+  }
   if (h->persist || !h->persist_wanted || h->persist_aborts == 0 || h->rearm_wait <= 0 || !h->Upf) return;
   if (++h->clean_steps <= h->rearm_wait) return;   // `rearm_wait` whole steps ran on the per-step kernels since the abort
   h->clean_steps = 0;
@@ -597,6 +617,14 @@ int repack(nasr_ctx* h) {
         const size_t o = k * (size_t)h->Hp * h->N4;
         launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
       }
+    if (h->wide) {   // column scales of every recurrent matrix, then the fp16-plane images of the wide forward kernel
+      std::vector<TphScaleJob> jobs;
+      for (size_t k = 0; k < h->off_u.size(); ++k)
+        jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, nullptr, nullptr, h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
+      launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
+      for (size_t k = 0; k < h->off_u.size(); ++k)
+        launch_repack_wide(h->P + h->off_u[k], h->Ucs + k * h->N4, h->Uw + k * wide_image_bytes(h->Hp), h->Hp, h->st);
+    }
   }
   {
     {   // scales of every weight matrix in two launches
@@ -973,6 +1001,17 @@ inline float* dg_of(nasr_ctx* h, int) { return h->dgbuf.as<float>(); }
 // ---- the per-timestep loops over steps [s0, s1), optionally replayed from a hipGraph -----------
 int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
   const LstmDims dm{h->T, h->B, h->Bp, h->H, h->Hp, h->D};
+  if (!bwd && h->wide && s0 == 0 && s1 == h->T && wide_supported(h->Hp, h->Bp)) {
+    for (int d = 0; d < h->D; ++d) {
+      const size_t k = (size_t)l * h->D + d;
+      launch_lstm_wide_fwd(dm, d, h->Uw + k * wide_image_bytes(h->Hp), h->Ucinv + k * h->N4, h->gates[l].as<float>(),
+                           h->cbuf[l].as<float>(), h->outb[l].as<float>(), h->seq_p, h->whx, h->wpart, h->wctl, h->perr,
+                           h->Gbase, h->cfg.forget_bias, st);
+    }
+    h->persist_used = true;
+    HIPCHK(h, hipGetLastError());
+    return NASR_OK;
+  }
   if (h->persist && s0 == 0 && s1 == h->T) {
     const size_t k = (size_t)l * h->D;
     if (!bwd)
@@ -1158,7 +1197,7 @@ int forward(nasr_ctx* h) {
     PhaseScope ps(h, PH_RECF);
     int rc = run_steps(h, l, false, 0, T, h->st);
     if (rc) return rc;
-    h->n_fwd_launch += h->persist ? 1 : T;
+    h->n_fwd_launch += h->persist ? 1 : (h->wide && wide_supported(h->Hp, h->Bp)) ? D : T;
   }
   if (h->has_post) {
     PhaseScope ps(h, PH_XPROJ);
@@ -1550,6 +1589,27 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       (void)hipMemsetAsync(h->xch, 0, persist_xch_floats(h->Hp) * 4, h->st);
     }
   }
+  {
+    const char* e = getenv("NASR_PERSIST");
+    const char* ew = getenv("NASR_WIDE");
+    h->wide = !h->persist && !(e && e[0] == '0') && !(ew && ew[0] == '0') && wide_supported(h->Hp, 16) &&
+              prop.multiProcessorCount == 256;
+    if (h->wide) {
+      const size_t nk = (size_t)h->L * h->D;
+      bool g2 = false;
+      size_t wsf = 0;
+      for (size_t k = 0; k < nk; ++k) wsf += tph_scale_ws_floats(h->Hp, h->N4);
+      if (wide_prepare() != hipSuccess || hipMalloc(&h->Uw, nk * wide_image_bytes(h->Hp)) != hipSuccess ||
+          hipMalloc(&h->whx, wide_hx_bytes(64)) != hipSuccess || hipMalloc(&h->wpart, wide_part_bytes(64)) != hipSuccess ||
+          hipMalloc(&h->wctl, sizeof(WideCtl)) != hipSuccess || hipMalloc(&h->Ucs, nk * h->N4 * 4) != hipSuccess ||
+          hipMalloc(&h->Ucinv, nk * h->N4 * 4) != hipSuccess || !h->scws.ensure(wsf * 4, &g2) ||
+          (!h->perr && hipHostMalloc(&h->perr, 64, hipHostMallocMapped) != hipSuccess))
+        return bail(NASR_ERR_HIP, "allocation of the wide persistent-recurrence buffers failed");
+      *h->perr = 0;
+      (void)hipMemsetAsync(h->whx, 0, wide_hx_bytes(64), h->st);
+      h->wide_wanted = true;
+    }
+  }
   h->gates.resize(h->L);
   h->outb.resize(h->L);
   h->cbuf.resize(h->L);
@@ -1585,6 +1645,10 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     const char* eb = getenv("NASR_BUCKET_DEFER");
     h->bucket_defer = !(eb && eb[0] == '0');
   }
+  if (h->wide) {
+    const char* er = getenv("NASR_PERSIST_REARM");
+    h->rearm_after = er && *er ? std::max<long long>(0, atoll(er)) : 200;
+  }
   *out = h;
   return NASR_OK;
 }
@@ -1605,6 +1669,10 @@ int nasr_destroy(nasr_handle h) {
   for (auto& b : h->Ybuf) b.release();
   for (auto& b : h->dYbuf) b.release();
   if (h->pctl) (void)hipFree(h->pctl);
+  if (h->Uw) (void)hipFree(h->Uw);
+  if (h->whx) (void)hipFree(h->whx);
+  if (h->wpart) (void)hipFree(h->wpart);
+  if (h->wctl) (void)hipFree(h->wctl);
   if (h->perr) (void)hipHostFree(h->perr);
   for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->OTTP0, &h->OTTP1, &h->GTP, &h->GTTP, &h->scws}) b->release();
   for (nasr_ctx::SV* v : {&h->sc15, &h->sc_x0r, &h->sc_x0c, &h->sc_gr, &h->sc_gc}) v->release();
@@ -2091,10 +2159,16 @@ int nasr_get_dropout_state(nasr_handle h, uint32_t* seed, uint32_t* counter) {
   return NASR_OK;
 }
 
-int nasr_get_recurrence_mode(nasr_handle h) { return h && h->persist ? 1 : 0; }
+int nasr_get_recurrence_mode(nasr_handle h) { return !h ? 0 : h->persist ? 1 : h->wide ? 2 : 0; }
 
 int nasr_set_recurrence_mode(nasr_handle h, int persistent) {
   if (!h) return NASR_ERR_ARG;
+  if (h->Uw) {   // a wide layer: the wide forward kernel on / off
+    HIPCHK(h, hipStreamSynchronize(h->st));
+    h->wide = persistent != 0;
+    h->wide_wanted = h->wide;
+    return repack(h);
+  }
   if (persistent && !h->persist_ok)
     return h->fail(NASR_ERR_STATE, "the persistent recurrence is not available on this device / hidden size");
   HIPCHK(h, hipStreamSynchronize(h->st));

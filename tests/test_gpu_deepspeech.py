@@ -121,21 +121,32 @@ def test_deepspeech_training_step_matches_oracle_adam():
 
 def test_reference_shape_constructs_and_steps():
     """networks/deepspeech.py at its own sizes (n_hidden 2048, BiLSTM 2048, 26-MFCC x 21 context), a short batch:
-    the per-step recurrence kernels serve Hp = 2048 (no persistent instantiation), loss finite and decreasing."""
+    the wide persistent forward kernel (lstm_wide.hip: one launch per direction) + the per-step BPTT serve Hp = 2048; loss
+    finite and decreasing, and the same steps on the per-step forward kernels give the same losses and parameters."""
     from neuralasr_amd.networks.deepspeech import DeepSpeech
     spec = O.ModelSpec(546, DeepSpeech.n_cell_dim, 1, True, 'concat', 29, pre=DeepSpeech.pre_widths(), post=DeepSpeech.n_hidden,
                        relu_clip=DeepSpeech.relu_clip, dropout=DeepSpeech.dropout)
     B, T = 4, 24
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1, Lmin=2, Lmax=4)
-    e = make_engine(spec, lr=1e-4)
-    assert e.recurrence_mode == 'per-step'
     rs = np.random.RandomState(0)
-    e.set_params((rs.randn(e.param_count) * 0.02).astype(np.float32))
-    l0 = e.train_step(feats, seq_len, labels, label_len)
-    l1 = e.train_step(feats, seq_len, labels, label_len)
-    l2 = e.train_step(feats, seq_len, labels, label_len)
-    assert np.isfinite([l0, l1, l2]).all() and l2 < l0
-    e.close()
+    runs = {}
+    for mode in ('wide-forward', 'per-step'):
+        e = make_engine(spec, lr=1e-4)
+        assert e.recurrence_mode == 'wide-forward'
+        if mode == 'per-step':
+            e.set_recurrence_mode(False)
+        assert e.recurrence_mode == mode
+        if 'p0' not in runs:
+            runs['p0'] = (rs.randn(e.param_count) * 0.02).astype(np.float32)
+        e.set_params(runs['p0'])
+        losses = [e.train_step(feats, seq_len, labels, label_len) for _ in range(3)]
+        assert np.isfinite(losses).all() and losses[2] < losses[0]
+        runs[mode] = (losses, e.get_params())
+        e.close()
+    np.testing.assert_allclose(runs['wide-forward'][0], runs['per-step'][0], rtol=2e-5)
+    d = runs['wide-forward'][1] - runs['per-step'][1]
+    # Adam's first steps move every weight by ~lr whatever its gradient: compare against that step size
+    assert np.abs(d).max() < 0.05 * 3e-4, np.abs(d).max()
 
 
 def _reference_spec():

@@ -5,6 +5,7 @@
 // Run:   tools/sb_wide [T=64] [B=32] [check=1]
 #include "kernels.h"
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -102,6 +103,18 @@ int main(int argc, char** argv) {
     }
     CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
     CK(hipEventElapsedTime(&msB, a, b));
+  }
+  if (getenv("WIDE_STAMPS")) {
+    std::vector<unsigned> hc(sizeof(WideCtl) / 4);
+    CK(hipMemcpy(hc.data(), ctl, sizeof(WideCtl), hipMemcpyDeviceToHost));
+    const unsigned* st_ = hc.data() + (offsetof(WideCtl, pflag) / 4) + 256 * 32 - 256;
+    const char* names[10] = {"loop-top", "h-poll", "h-load+lds", "barrier1", "mfma", "part-store+ack", "part-poll", "part-load+lds", "barrier2", "cell..barrier3"};
+    printf("cycles per step (100 MHz s_memtime ticks x 24 ~ core cycles at 2.4 GHz):\n");
+    for (int i = 0; i < 10; ++i) {
+      printf("  %-16s", names[i]);
+      for (int wv = 0; wv < 16; ++wv) printf(" %6.1f", st_[wv * 10 + i] / (double)T);
+      printf("\n");
+    }
   }
   printf("T %d B %d: per-step kernels %.3f ms (%.2f us/step), wide persistent %.3f ms (%.2f us per direction-step)\n", T, B, msA,
          msA * 1e3 / T, msB, msB * 1e3 / (2 * T));
