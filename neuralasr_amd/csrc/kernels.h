@@ -130,7 +130,8 @@ void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* 
 // ---- wide persistent forward recurrence (lstm_wide.hip): Hp = 2048, one launch per direction over all 256 CUs ----
 struct WideCtl {               // device words, zeroed before every launch
   unsigned xcc_count[8];
-  unsigned error;              // bit 0: a bounded spin gave up, bit 1: placement is not 32 workgroups on each of 8 XCDs
+  unsigned error;              // bit 0: a bounded spin gave up, bit 1: placement is not 32 workgroups on each of 8 XCDs,
+                               // bit 2 (BPTT): dG left the fp16 range of its planes
   unsigned pad[23];
   unsigned hflag[8 * 32];      // [XCD x][member]: timesteps whose h this workgroup has published
   unsigned pflag[256 * 32];    // [destination workgroup][source XCD] (8 of 32 words used: one 128-byte line per inbox)
@@ -151,6 +152,16 @@ void launch_repack_wide(const float* U, const float* cs, void* Uw, int Hp, hipSt
 void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float* cinv, float* gates, float* cbuf,
                           float* out, const int* seq_len, void* hx, float* part, WideCtl* ctl, unsigned* sticky,
                           float* fault, float forget_bias, hipStream_t st);
+
+// BPTT of the same layer: Uwb = the backward image (U^T fragments under per-row scales rs [Hp]; rinv = 1 / rs), srow [D][Bp]
+// = power-of-two scale of dG per (direction, utterance) from launch_wide_row_scales; inbox = the forward kernel's partial-sum
+// buffer (wide_part_bytes), px = wide_px_bytes
+size_t wide_px_bytes(int Bp);
+void launch_repack_wide_bwd(const float* U, const float* rs, void* Uwb, int Hp, hipStream_t st);
+void launch_wide_row_scales(const LstmDims& dm, const float* dout, const int* seq_len, float* srow, hipStream_t st);
+void launch_lstm_wide_bwd(const LstmDims& dm, int d, const void* Uwb, const float* rinv, const float* srow,
+                          const float* gates, float* dgbuf, const float* cbuf, const float* dout, const int* seq_len,
+                          float* inbox, void* px, WideCtl* ctl, unsigned* sticky, float* fault, hipStream_t st);
 
 // ---- DeepSpeech dense stages (dense.hip): clipped ReLU + hash-defined dropout, in place ----
 void launch_dense_act(float* z, int R, int Bp, int B, int W, int ld, float clip, float p, uint32_t seed, uint32_t counter,

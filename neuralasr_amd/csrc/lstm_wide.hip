@@ -389,6 +389,340 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
   if (aborted && tid == 0) wide_raise(ctl, sticky, gm.fault, 1u);
 }
 
+// ------------------------------------------------------------------ BPTT
+// The same 2-D grid with the two hand-offs the other way round.  Per timestep (s descending, k = T-1-s counts them):
+//   1. dG of step k-1 - [rows x 32 gate columns] from each of the 8 workgroups (x', nb) that own this workgroup's columns -
+//      arrives across the XCDs as two fp16 planes of dG * S_row (power-of-two scale per utterance, wide_row_scale_kernel);
+//      sentinel-polled inboxes as in the forward kernel, one copy per reader;
+//   2. partial dh of the XCD's 256 units over this workgroup's 256 gate columns: A = dG planes, B = U^T planes under
+//      per-unit (row of U) scales, three products; wave w owns units [32w, 32w+32) of the slice = members 4w .. 4w+3;
+//   3. XCD-local reduce-scatter through the L2: 32 sources x [rows x 8 units] per workgroup, flag per (source, wave);
+//   4. cell backward of the 8 own units (dc in a register for all T), dG to HBM (frame-indexed, for the weight-gradient
+//      GEMMs) and, as planes, to the 8 inboxes.
+// A dG * S_row beyond the fp16 range raises error bit 2: the launch drains and the step is void (the caller repeats it on
+// the per-step kernels).
+//
+// Uwb as 16-byte units [8 x][32 nb][8 w][8 kt][2 nt][2 plane][64 lane]: lane l holds the 8 halfs
+//   U[row = KS*x + 32*w + 16*nt + (l&15)][col = 4*(KS*kt + 8*nb + 2*(l>>4) + (j>>2)) + (j&3)] * rs[row],  j = 0..7.
+__global__ __launch_bounds__(256) void repack_wide_bwd_kernel(const float* __restrict__ U, const float* __restrict__ rs,
+                                                              u32x4* __restrict__ Uwb, int Hp) {
+  const int KS = Hp / 8, N4 = 4 * Hp;
+  const int64_t total = (int64_t)8 * 32 * 8 * 8 * 2 * 64;   // (x, nb, w, kt, nt, lane)
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(e & 63);
+    int64_t r = e >> 6;
+    const int nt = (int)(r & 1); r >>= 1;
+    const int kt = (int)(r & 7); r >>= 3;
+    const int w = (int)(r & 7); r >>= 3;
+    const int nb = (int)(r & 31), x = (int)(r >> 5);
+    const int row = KS * x + 32 * w + 16 * nt + (l & 15);
+    const float sc = rs[row];
+    const float* src = U + (size_t)row * N4 + 4 * (KS * kt + 8 * nb + 2 * (l >> 4));   // 8 consecutive columns: 2 units x 4 gates
+    h8 p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = src[j] * sc;
+      const _Float16 a = (_Float16)v;
+      p1[j] = a;
+      p2[j] = (_Float16)(v - (float)a);
+    }
+    u32x4* dst = Uwb + (e >> 6) * 128 + l;
+    dst[0] = __builtin_bit_cast(u32x4, p1);
+    dst[64] = __builtin_bit_cast(u32x4, p2);
+  }
+}
+
+void launch_repack_wide_bwd(const float* U, const float* rs, void* Uwb, int Hp, hipStream_t st) {
+  hipLaunchKernelGGL(repack_wide_bwd_kernel, dim3(2048), dim3(256), 0, st, U, rs, reinterpret_cast<u32x4*>(Uwb), Hp);
+}
+
+// srow [D][Bp]: power-of-two scale per (direction, utterance) that brings the largest |dOut| of that utterance's frames into
+// [2^5, 2^6) (1 where the utterance has no gradient): dG = O(dOut) then has 2^10 of headroom in fp16.  One block per (b, d).
+__global__ __launch_bounds__(256) void wide_row_scale_kernel(const float* __restrict__ dout, const int* __restrict__ seq_len,
+                                                             float* __restrict__ srow, int T, int Bp, int Hp, int D) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, d = blockIdx.y, DH = D * Hp;
+  const int len = seq_len[b] < T ? seq_len[b] : T;
+  float m = 0.f;
+  for (int t = 0; t < len; ++t) {
+    const float* row = dout + ((size_t)t * Bp + b) * DH + d * Hp;
+    for (int j = threadIdx.x; j < Hp; j += 256) m = fmaxf(m, fabsf(row[j]));
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mx = red[0];
+    float sc = 1.f;
+    if (mx > 0.f && mx < 3e38f) {
+      int e;
+      (void)frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+      sc = ldexpf(1.f, 6 - e);              // mx * sc in [2^5, 2^6)
+    }
+    srow[d * Bp + b] = sc;
+  }
+}
+
+// LDS map (16-byte units): A [8 kt][MT][2 p][64] | PB [32 src][32*MT] | sinv [16*MT floats] | info
+template <int MT>
+struct WideLdsB {
+  static constexpr int A = 0, PB = A + 8 * MT * 2 * 64, SINV = PB + 32 * 32 * MT, INFO = SINV + 4 * MT, END = INFO + 4;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
+    const u32x4* __restrict__ Uwb,      // this direction's backward image
+    const float* __restrict__ gates,    // activations si,tj,sf,so [R][D*N4]
+    float* dgbuf,                       // dG, frame-indexed [R][D*N4]
+    const float* __restrict__ cbuf, const float* __restrict__ dout, const int* __restrict__ seq_len,
+    u32x4* inbox,                       // [2 parity][256 dest][8 src][MT][2 plane][64 lane]: dG planes in A-fragment order
+    f32x4* px,                          // [2 parity][8 x][32 dest][32 src][32*MT]: partial dh, [m][unit 8][q 4] x 4 rows
+    WideCtl* ctl, unsigned* sticky, WideGeom gm, const float* __restrict__ rinv,   // [Hp] 1 / row scale of U
+    const float* __restrict__ srow) {   // [Bp] dG scale of this direction
+  extern __shared__ __attribute__((aligned(16))) u32x4 wlds[];
+  using L = WideLdsB<MT>;
+  constexpr int ROWS = 16 * MT, PU = 32 * MT;     // PU: 16-byte units of one [rows x 8 units] partial block
+  u32x4* Alds = wlds + L::A;
+  f32x4* PBlds = reinterpret_cast<f32x4*>(wlds + L::PB);
+  unsigned* info = reinterpret_cast<unsigned*>(wlds + L::INFO);
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  if (tid == 0) {
+    const unsigned xi = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+    info[0] = xi;
+    info[1] = xi < 8 ? atomicAdd(&ctl->xcc_count[xi], 1u) : 0xffffu;
+    info[2] = 0;
+    info[3] = 0;
+  }
+  __syncthreads();
+  const int x = (int)info[0], nb = (int)info[1];
+  if (x >= 8 || nb >= 32) {
+    if (tid == 0) wide_raise(ctl, sticky, gm.fault, 2u);
+    return;
+  }
+  const int T = gm.T, Bp = gm.Bp, Hp = gm.Hp, D = gm.D, d = gm.d;
+  const int KS = Hp / 8, N4 = 4 * Hp, DH = D * Hp, DN = D * N4;
+  const int me = x * 32 + nb;
+
+  // ---- this wave's block of U^T: units [32w, 32w+32) of the slice x over the workgroup's 256 gate columns
+  h8 ub[8][2][2];
+  {
+    const u32x4* up = Uwb + ((size_t)(me * 8 + w) * 8) * 4 * 64 + lane;
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ub[kt][nt][p] = __builtin_bit_cast(h8, up[((kt * 2 + nt) * 2 + p) * 64]);
+  }
+  // output scale of C element (row 16m + 4(l>>4) + r, unit 32w + 16nt + (l&15)): 1 / (row scale of U x S of the utterance)
+  float oun[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) oun[nt] = rinv[KS * x + 32 * w + 16 * nt + (lane & 15)];
+  float* sinv = reinterpret_cast<float*>(wlds + L::SINV);     // 1 / S of every utterance row (read back per tile)
+  if (tid < ROWS) sinv[tid] = tid < Bp ? 1.f / srow[tid] : 1.f;
+  __syncthreads();
+  gu32* bflag = (gu32*)ctl->pflag;              // [(x*32 + src)*32 + wave]
+
+  // ---- cell threads
+  const bool cell = tid < 8 * ROWS;
+  const int cb = tid >> 3, ci = tid & 7;
+  const int u = KS * x + 8 * nb + ci;
+  const bool rowok = cell && cb < Bp;
+  const int len = rowok ? seq_len[cb] : 0;
+  const float sb = rowok ? srow[cb] : 1.f;
+  float dc = 0.f;
+  bool aborted = false;
+  const f32x4 sent = __builtin_bit_cast(f32x4, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
+
+  for (int k = 0; k < T; ++k) {
+    const int s = T - 1 - k, par = k & 1;
+    bool ok = true;
+    // per-frame operands of the cell backward: in flight during the gather / product phases.  Unconditional loads
+    // (a masked cell reads frame 0 of its row and is zeroed below).
+    const bool valid = rowok && s < len;
+    const int tb = valid ? (d ? len - 1 - s : s) : 0;
+    const unsigned r_ = (unsigned)(tb * Bp + (rowok ? cb : 0));
+    const unsigned rp = s > 0 ? (d ? r_ + Bp : r_ - Bp) : r_;
+    f32x4 act = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cc = 0.f, cpv = 0.f, dh = 0.f;
+    auto load_cell = [&]() {
+      if (cell) {
+        act = *reinterpret_cast<const f32x4*>(gates + (r_ * (unsigned)DN + (unsigned)(d * N4 + 4 * u)));
+        cc = cbuf[r_ * (unsigned)DH + (unsigned)(d * Hp + u)];
+        cpv = cbuf[(valid ? rp : r_) * (unsigned)DH + (unsigned)(d * Hp + u)];
+        dh = dout[r_ * (unsigned)DH + (unsigned)(d * Hp + u)];
+      }
+    };
+    if (k == 0) load_cell();
+    if (k > 0) {
+      // 1. dG of step k-1 from source slice w (its 32 gate columns of this workgroup's 256): the own slice is already in LDS
+      if (w != x) {
+        u32x4* src = inbox + ((((size_t)((k - 1) & 1) * 256 + me) * 8 + w) * MT * 2) * 64 + lane;
+        u32x4 v[MT][2];
+        ok = false;
+        for (unsigned n = 0; n < WIDE_SPIN; ++n) {
+          v[MT - 1][1] = ld16_sc1(src + ((MT - 1) * 2 + 1) * 64);
+          wait_vm0(v[MT - 1][1]);
+          const u32x4 q = v[MT - 1][1];
+          if (!__all(q.x != 0xffffffffu && q.y != 0xffffffffu && q.z != 0xffffffffu && q.w != 0xffffffffu)) continue;
+          bool all = true;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              if (m != MT - 1 || p != 1) v[m][p] = ld16_sc1(src + (m * 2 + p) * 64);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              if (m != MT - 1 || p != 1) {
+                wait_vm0(v[m][p]);
+                const u32x4 t = v[m][p];
+                all = all && t.x != 0xffffffffu && t.y != 0xffffffffu && t.z != 0xffffffffu && t.w != 0xffffffffu;
+              }
+          if (__all(all)) { ok = true; break; }
+        }
+        if (s == gm.inject && me == 0) ok = false;
+        if (ok) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              Alds[((w * MT + m) * 2 + p) * 64 + lane] = v[m][p];
+              st16_sc1(src + (m * 2 + p) * 64, sent);
+            }
+        } else {
+          info[2] = 1;
+        }
+      }
+    }
+    __syncthreads();                                        // #1: dG of step k-1 is in LDS (all 8 column groups)
+    if (k > 0 && !info[2]) {
+      // 2. partial dh of units [32w, 32w+32) of the slice; each 16 x 16 tile goes to the XCD's exchange buffer at once
+      f32x4* pdst = px + (((size_t)(par * 8 + x) * 32) * 32 + nb) * PU;        // + dest * 32 * PU
+      wstatic_for<0, MT>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        // both 16 x 16 tiles of this M tile together; the A fragments of k-tile kt+1 are read while kt multiplies (the
+        // scheduling barriers keep the compiler from hoisting every read to the top, which costs 64 registers per M tile)
+        f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        h8 c0 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 0) * 64 + lane]);
+        h8 c1 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 1) * 64 + lane]);
+        wstatic_for<0, 8>([&](auto ktc) {
+          constexpr int kt = decltype(ktc)::value;
+          h8 n0 = c0, n1 = c1;
+          if constexpr (kt < 7) {
+            n0 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 0) * 64 + lane]);
+            n1 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 1) * 64 + lane]);
+          }
+          t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ub[kt][0][0], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ub[kt][1][0], t1, 0, 0, 0);
+          t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ub[kt][0][1], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ub[kt][1][1], t1, 0, 0, 0);
+          t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ub[kt][0][0], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ub[kt][1][0], t1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          c0 = n0;
+          c1 = n1;
+        });
+        const f32x4 si = *reinterpret_cast<const f32x4*>(sinv + 16 * m + 4 * (lane >> 4));
+        t0 *= si * oun[0];
+        t1 *= si * oun[1];
+        // unit 32w + 16nt + (l&15) belongs to member 4w + 2nt + ((l&15)>>3), its unit (l&7); rows 16m + 4(l>>4) + 0..3
+        const int dest = 4 * w + ((lane & 15) >> 3);
+        f32x4* pd = pdst + (size_t)dest * 32 * PU + ((m * 8 + (lane & 7)) * 4 + (lane >> 4));   // plain stores: this XCD's L2
+        pd[0] = t0;
+        pd[(size_t)2 * 32 * PU] = t1;
+      });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // acknowledged before the flag goes out
+      if (lane == 0) bflag[me * 32 + w] = (unsigned)k;
+      load_cell();                                           // in flight under the flag poll and the gather below
+      // 3. the 32 partial sums of the own 8 units: wave w fetches sources 4w .. 4w+3 (each from the wave that owns this
+      // workgroup's units: nb >> 2)
+      ok = wpoll_ge(bflag + (x * 32 + 4 * w + (lane & 3)) * 32 + (nb >> 2), lane < 4, (unsigned)k);
+      if (ok) {
+        const f32x4* src = px + (((size_t)(par * 8 + x) * 32 + nb) * 32 + 4 * w) * PU;
+        constexpr int NL = (4 * PU + 63) / 64;               // 16-byte loads per lane for 4 sources
+        u32x4 v[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+          if (lane + 64 * j < 4 * PU) v[j] = ld16_sc1(src + lane + 64 * j);
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+          if (lane + 64 * j < 4 * PU) wait_vm0(v[j]);
+#pragma unroll
+        for (int j = 0; j < NL; ++j)
+          if (lane + 64 * j < 4 * PU) PBlds[4 * w * PU + lane + 64 * j] = __builtin_bit_cast(f32x4, v[j]);
+      } else {
+        info[2] = 1;
+      }
+    }
+    __syncthreads();                                        // #2: the 32 partial sums are in LDS
+    const unsigned abort_word = info[2];
+    // 4. cell backward of (row cb, unit ci)
+    if (cell) {
+      float dhs = dh;
+      if (k > 0) {
+        const float* pl = reinterpret_cast<const float*>(PBlds) + (((cb >> 4) * 8 + ci) * 4 + ((cb & 15) >> 2)) * 4 + (cb & 3);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < 32; sx += 2) { s0 += pl[sx * PU * 4]; s1 += pl[(sx + 1) * PU * 4]; }
+        dhs += s0 + s1;
+      }
+      f32x4 dg = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float dcn = 0.f;
+      if (valid) {
+        if (s == 0) cpv = 0.f;
+        const float tc = wtanh(cc);
+        const float dct = dc + dhs * act.w * (1.f - tc * tc);
+        dg.x = dct * act.y * act.x * (1.f - act.x);
+        dg.y = dct * act.x * (1.f - act.y * act.y);
+        dg.z = dct * cpv * act.z * (1.f - act.z);
+        dg.w = dhs * tc * act.w * (1.f - act.w);
+        dcn = dct * act.z;
+      }
+      dc = dcn;
+      // the planes of dG * S_row in A-fragment order: (row cb, columns 4ci .. 4ci+3) of the 32 = unit (cb&15) + 16*(ci>>1) of
+      // M tile cb>>4, halfs 4*(ci&1) ..
+      const f32x4 sv = dg * sb;
+      if (!(fabsf(sv.x) < 32768.f && fabsf(sv.y) < 32768.f && fabsf(sv.z) < 32768.f && fabsf(sv.w) < 32768.f)) info[3] = 1;
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 p1, p2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 a = (_Float16)sv[j];
+        p1[j] = a;
+        p2[j] = (_Float16)(sv[j] - (float)a);
+      }
+      // own column group (kt = x) of the next step's A operand: straight into LDS
+      h4* ap = reinterpret_cast<h4*>(Alds + ((x * MT + (cb >> 4)) * 2) * 64 + (cb & 15) + 16 * (ci >> 1)) + (ci & 1);
+      ap[0] = p1;
+      ap[64 * 2] = p2;                                       // plane 1: 64 units of 16 bytes = 128 h4 further
+      // dG for the weight-gradient GEMMs (zero at masked steps: the frame of a masked step is frame s itself)
+      if (rowok) {
+        const unsigned row = valid ? r_ : (unsigned)(s * Bp + cb);
+        *reinterpret_cast<f32x4*>(dgbuf + (row * (unsigned)DN + (unsigned)(d * N4 + 4 * u))) = dg;
+      }
+    }
+    __syncthreads();                                        // #3: the own dG tile is complete in LDS
+    if (info[3]) { if (tid == 0) wide_raise(ctl, sticky, gm.fault, 4u); aborted = true; }
+    // 5. publish the tile to the 7 other workgroups that hold these units' columns (wave w -> XCD w)
+    if (w != x && k + 1 < T && !aborted) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the sentinel stores of this wave's gather are acknowledged)
+      u32x4* dst = inbox + ((((size_t)par * 256 + (w * 32 + nb)) * 8 + x) * MT * 2) * 64 + lane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          st16_sc1(dst + (m * 2 + p) * 64, __builtin_bit_cast(f32x4, Alds[((x * MT + m) * 2 + p) * 64 + lane]));
+    }
+    if (abort_word || aborted) { aborted = true; break; }
+  }
+  if (aborted && tid == 0) wide_raise(ctl, sticky, gm.fault, 1u);
+}
+
 hipError_t wide_prepare() {
   hipError_t e = hipSuccess;
 #define NASR_WIDE_ATTR(MTV)                                                                                         \
@@ -400,7 +734,43 @@ hipError_t wide_prepare() {
   NASR_WIDE_ATTR(3);
   NASR_WIDE_ATTR(4);
 #undef NASR_WIDE_ATTR
+#define NASR_WIDE_ATTR(MTV)                                                                                         \
+  if (e == hipSuccess)                                                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wide_bwd_kernel<MTV>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, WideLdsB<MTV>::END * 16)
+  NASR_WIDE_ATTR(1);
+  NASR_WIDE_ATTR(2);
+  NASR_WIDE_ATTR(3);
+  NASR_WIDE_ATTR(4);
+#undef NASR_WIDE_ATTR
   return e;
+}
+
+size_t wide_px_bytes(int Bp) { return (size_t)2 * 8 * 32 * 32 * (32 * (Bp / 16)) * 16; }
+
+void launch_wide_row_scales(const LstmDims& dm, const float* dout, const int* seq_len, float* srow, hipStream_t st) {
+  hipLaunchKernelGGL(wide_row_scale_kernel, dim3(dm.Bp, dm.D), dim3(256), 0, st, dout, seq_len, srow, dm.T, dm.Bp, dm.Hp, dm.D);
+}
+
+void launch_lstm_wide_bwd(const LstmDims& dm, int d, const void* Uwb, const float* rinv, const float* srow,
+                          const float* gates, float* dgbuf, const float* cbuf, const float* dout, const int* seq_len,
+                          float* inbox, void* px, WideCtl* ctl, unsigned* sticky, float* fault, hipStream_t st) {
+  (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
+  (void)hipMemsetAsync(inbox, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
+  WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, fault};
+  if (const char* e = getenv("NASR_WIDE_FAULT_BWD")) gm.inject = atoi(e);
+  const int MT = dm.Bp / 16;
+#define NASR_WIDE(MTV)                                                                                               \
+  hipLaunchKernelGGL((lstm_wide_bwd_kernel<MTV>), dim3(256), dim3(512), WideLdsB<MTV>::END * 16, st,                 \
+                     reinterpret_cast<const u32x4*>(Uwb), gates, dgbuf, cbuf, dout, seq_len,                           \
+                     reinterpret_cast<u32x4*>(inbox), reinterpret_cast<f32x4*>(px), ctl, sticky, gm, rinv, srow + (size_t)d * dm.Bp)
+  switch (MT) {
+    case 1: NASR_WIDE(1); break;
+    case 2: NASR_WIDE(2); break;
+    case 3: NASR_WIDE(3); break;
+    default: NASR_WIDE(4); break;
+  }
+#undef NASR_WIDE
 }
 
 void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float* cinv, float* gates, float* cbuf,

@@ -177,5 +177,82 @@ int main(int argc, char** argv) {
     }
     printf(herr == 0 && m < 1e-4 && m2 < 1e-4 && m3 < 1e-4 ? "OK\n" : "MISMATCH\n");
   }
+  // ================= BPTT: per-step kernels vs the wide persistent kernel, on the forward results above
+  {
+    std::vector<float> hrs((size_t)D * Hp), hri((size_t)D * Hp), hdo(R * DH);
+    for (int d = 0; d < D; ++d)
+      for (int k = 0; k < Hp; ++k) {
+        float m = 0.f;
+        for (int c = 0; c < N4; ++c) m = std::fmax(m, std::fabs(hU[((size_t)d * Hp + k) * N4 + c]));
+        int e;
+        std::frexp(m, &e);
+        hrs[(size_t)d * Hp + k] = std::ldexp(1.f, 15 - e);
+        hri[(size_t)d * Hp + k] = std::ldexp(1.f, e - 15);
+      }
+    for (auto& v : hdo) v = (rand() / (float)RAND_MAX - 0.5f) * 2e-3f;
+    float *rs, *ri, *dout, *dgA, *dgB, *par, *dcs, *srow;
+    void *Uwb, *px;
+    const int np = lstm_bwd_partials(Hp);
+    const size_t ps = (size_t)D * np * Bp * Hp;
+    CK(hipMalloc(&rs, hrs.size() * 4)); CK(hipMalloc(&ri, hri.size() * 4)); CK(hipMalloc(&dout, hdo.size() * 4));
+    CK(hipMalloc(&dgA, hg.size() * 4)); CK(hipMalloc(&dgB, hg.size() * 4)); CK(hipMalloc(&par, 2 * ps * 4));
+    CK(hipMalloc(&dcs, 2 * hsz * 4)); CK(hipMalloc(&srow, (size_t)D * Bp * 4));
+    CK(hipMalloc(&Uwb, D * wide_image_bytes(Hp))); CK(hipMalloc(&px, wide_px_bytes(Bp)));
+    CK(hipMemcpy(rs, hrs.data(), hrs.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ri, hri.data(), hri.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dout, hdo.data(), hdo.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(px, 0, wide_px_bytes(Bp)));
+    for (int d = 0; d < D; ++d)
+      launch_repack_wide_bwd(U + (size_t)d * Hp * N4, rs + (size_t)d * Hp, (char*)Uwb + d * wide_image_bytes(Hp), Hp, st);
+    CK(hipStreamSynchronize(st));
+    float msC = 0, msD = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipMemsetAsync(dgA, 0xff, hg.size() * 4, st));
+      CK(hipMemsetAsync(par, 0, 2 * ps * 4, st)); CK(hipMemsetAsync(dcs, 0, 2 * hsz * 4, st));
+      CK(hipEventRecord(a, st));
+      for (int s = T - 1; s >= 0; --s) {
+        const int k = T - 1 - s;
+        launch_lstm_bwd_step(dm, s, Ub, par + (k & 1) * ps, par + ((k + 1) & 1) * ps, gatesA, dgA, cA, dout, dcs + (k & 1) * hsz,
+                             dcs + ((k + 1) & 1) * hsz, seq, st);
+      }
+      CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&msC, a, b));
+    }
+    unsigned herr2 = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemsetAsync(dgB, 0xff, hg.size() * 4, st));
+      CK(hipEventRecord(a, st));
+      launch_wide_row_scales(dm, dout, seq, srow, st);
+      for (int d = 0; d < D; ++d) {
+        launch_lstm_wide_bwd(dm, d, (char*)Uwb + d * wide_image_bytes(Hp), ri + (size_t)d * Hp, srow, gatesA, dgB, cA, dout, seq, part,
+                             px, ctl, nullptr, nullptr, st);
+        if (rep == 0) {
+          CK(hipStreamSynchronize(st));
+          WideCtl hc;
+          CK(hipMemcpy(&hc, ctl, sizeof(unsigned) * 16, hipMemcpyDeviceToHost));
+          herr2 |= hc.error;
+          printf("BPTT direction %d: error word %u\n", d, hc.error);
+        }
+      }
+      CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+      CK(hipEventElapsedTime(&msD, a, b));
+    }
+    printf("BPTT T %d B %d: per-step kernels %.3f ms (%.2f us/step), wide persistent %.3f ms (%.2f us per direction-step)\n", T, B,
+           msC, msC * 1e3 / T, msD, msD * 1e3 / (2 * T));
+    if (check) {
+      std::vector<float> ga(hg.size()), gb(hg.size());
+      CK(hipMemcpy(ga.data(), dgA, ga.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gb.data(), dgB, gb.size() * 4, hipMemcpyDeviceToHost));
+      double ref, m = 0, nrm = 0, dn = 0;
+      long nbad = 0;
+      for (size_t i = 0; i < ga.size(); ++i) {
+        const double df = (double)ga[i] - gb[i];
+        if (!(std::fabs(df) <= 1e30)) { if (nbad < 5) printf("  non-finite / missing at %zu: ref %g got %g\n", i, ga[i], gb[i]); ++nbad; continue; }
+        m = std::fmax(m, std::fabs(df)); nrm += (double)ga[i] * ga[i]; dn += df * df;
+      }
+      (void)ref;
+      printf("dG   max |diff| %.3e, rel L2 %.3e, %ld bad values\n", m, std::sqrt(dn / (nrm + 1e-300)), nbad);
+      printf(herr2 == 0 && nbad == 0 && std::sqrt(dn / (nrm + 1e-300)) < 1e-5 ? "BPTT OK\n" : "BPTT MISMATCH\n");
+    }
+  }
   return 0;
 }
