@@ -134,9 +134,13 @@ struct nasr_ctx {
   // with U resident in the registers of all 256 CUs; the BPTT of such a layer stays on the per-step kernels.  NASR_WIDE=0
   // (or NASR_PERSIST=0) keeps the per-step forward kernels.  Shares the abort / re-arm bookkeeping above.
   bool wide = false, wide_wanted = false;
-  unsigned char* Uw = nullptr;         // [L][D] operand images (wide_image_bytes each)
+  unsigned char* Uw = nullptr;         // [L][D] forward operand images (wide_image_bytes each)
+  unsigned char* Uwb = nullptr;        // [L][D] BPTT operand images (U^T fragments under per-row scales)
+  float *Urs = nullptr, *Urinv = nullptr;   // [L*D][Hp] row scales of every recurrent matrix and their inverses
+  float* wsrow = nullptr;              // [D][64] dG scale per (direction, utterance) of the running BPTT pass
   void* whx = nullptr;                 // h exchange
-  float* wpart = nullptr;              // partial-sum exchange
+  float* wpart = nullptr;              // cross-XCD inboxes: partial sums (forward) / dG planes (BPTT)
+  void* wpx = nullptr;                 // BPTT: partial dh through the XCD's L2
   WideCtl* wctl = nullptr;
   unsigned* perr = nullptr;            // host-mapped sticky error word
   std::string err;
@@ -620,10 +624,13 @@ int repack(nasr_ctx* h) {
     if (h->wide) {   // column scales of every recurrent matrix, then the fp16-plane images of the wide forward kernel
       std::vector<TphScaleJob> jobs;
       for (size_t k = 0; k < h->off_u.size(); ++k)
-        jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, nullptr, nullptr, h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
+        jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, h->Urs + k * h->Hp, h->Urinv + k * h->Hp,
+                        h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
       launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
-      for (size_t k = 0; k < h->off_u.size(); ++k)
+      for (size_t k = 0; k < h->off_u.size(); ++k) {
         launch_repack_wide(h->P + h->off_u[k], h->Ucs + k * h->N4, h->Uw + k * wide_image_bytes(h->Hp), h->Hp, h->st);
+        launch_repack_wide_bwd(h->P + h->off_u[k], h->Urs + k * h->Hp, h->Uwb + k * wide_image_bytes(h->Hp), h->Hp, h->st);
+      }
     }
   }
   {
@@ -1012,6 +1019,18 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
     HIPCHK(h, hipGetLastError());
     return NASR_OK;
   }
+  if (bwd && h->wide && s0 == 0 && s1 == h->T && wide_supported(h->Hp, h->Bp)) {
+    launch_wide_row_scales(dm, dout_of(h, l), h->seq_p, h->wsrow, st);
+    for (int d = 0; d < h->D; ++d) {
+      const size_t k = (size_t)l * h->D + d;
+      launch_lstm_wide_bwd(dm, d, h->Uwb + k * wide_image_bytes(h->Hp), h->Urinv + k * h->Hp, h->wsrow,
+                           h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(), dout_of(h, l), h->seq_p, h->wpart,
+                           h->wpx, h->wctl, h->perr, h->Gbase, st);
+    }
+    h->persist_used = true;
+    HIPCHK(h, hipGetLastError());
+    return NASR_OK;
+  }
   if (h->persist && s0 == 0 && s1 == h->T) {
     const size_t k = (size_t)l * h->D;
     if (!bwd)
@@ -1361,12 +1380,12 @@ int backward(nasr_ctx* h) {
   }
   h->n_bwd_launch = 0;
   for (int l = h->L - 1; l >= 0; --l) {
-    const bool defer = h->persist && h->bucket_defer;
+    const bool defer = (h->persist || h->wide) && h->bucket_defer;
     {
       PhaseScope ps(h, PH_RECB);
       int rc = run_steps(h, l, true, 0, T, h->st);
       if (rc) return rc;
-      h->n_bwd_launch += h->persist ? 1 : T;
+      h->n_bwd_launch += h->persist ? 1 : (h->wide && wide_supported(h->Hp, h->Bp)) ? D : T;
     }
     if (defer && l + 1 < h->L && h->bucket_of_layer[l + 1] >= 0)   // the layer above's bucket, held back over this launch
       HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l + 1]], h->st));
@@ -1601,12 +1620,16 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       for (size_t k = 0; k < nk; ++k) wsf += tph_scale_ws_floats(h->Hp, h->N4);
       if (wide_prepare() != hipSuccess || hipMalloc(&h->Uw, nk * wide_image_bytes(h->Hp)) != hipSuccess ||
           hipMalloc(&h->whx, wide_hx_bytes(64)) != hipSuccess || hipMalloc(&h->wpart, wide_part_bytes(64)) != hipSuccess ||
-          hipMalloc(&h->wctl, sizeof(WideCtl)) != hipSuccess || hipMalloc(&h->Ucs, nk * h->N4 * 4) != hipSuccess ||
+          hipMalloc(&h->wctl, sizeof(WideCtl)) != hipSuccess || hipMalloc(&h->Uwb, nk * wide_image_bytes(h->Hp)) != hipSuccess ||
+          hipMalloc(&h->wpx, wide_px_bytes(64)) != hipSuccess || hipMalloc(&h->Urs, nk * h->Hp * 4) != hipSuccess ||
+          hipMalloc(&h->Urinv, nk * h->Hp * 4) != hipSuccess || hipMalloc(&h->wsrow, 2 * 64 * 4) != hipSuccess ||
+          hipMalloc(&h->Ucs, nk * h->N4 * 4) != hipSuccess ||
           hipMalloc(&h->Ucinv, nk * h->N4 * 4) != hipSuccess || !h->scws.ensure(wsf * 4, &g2) ||
           (!h->perr && hipHostMalloc(&h->perr, 64, hipHostMallocMapped) != hipSuccess))
         return bail(NASR_ERR_HIP, "allocation of the wide persistent-recurrence buffers failed");
       *h->perr = 0;
       (void)hipMemsetAsync(h->whx, 0, wide_hx_bytes(64), h->st);
+      (void)hipMemsetAsync(h->wpx, 0, wide_px_bytes(64), h->st);
       h->wide_wanted = true;
     }
   }
@@ -1670,6 +1693,10 @@ int nasr_destroy(nasr_handle h) {
   for (auto& b : h->dYbuf) b.release();
   if (h->pctl) (void)hipFree(h->pctl);
   if (h->Uw) (void)hipFree(h->Uw);
+  if (h->Uwb) (void)hipFree(h->Uwb);
+  if (h->wpx) (void)hipFree(h->wpx);
+  for (float* p : {h->Urs, h->Urinv, h->wsrow})
+    if (p) (void)hipFree(p);
   if (h->whx) (void)hipFree(h->whx);
   if (h->wpart) (void)hipFree(h->wpart);
   if (h->wctl) (void)hipFree(h->wctl);
