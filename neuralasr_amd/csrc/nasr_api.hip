@@ -322,7 +322,7 @@ int persist_check(nasr_ctx* h) {
   h->rearm_wait = h->persist_aborts <= 1 ? h->rearm_after : std::min<int64_t>(h->rearm_wait * 2, (int64_t)1 << 20);
   (void)repack(h);   // operand images of the per-step kernels
   return h->fail(NASR_ERR_HIP, "persistent recurrence aborted (code " + std::to_string(code) +
-                                   ": 1 = hand-off timeout, 2 = workgroup placement); the results of this step are "
+                                   ": 1 = hand-off timeout, 2 = workgroup placement, 4 = dG beyond its fp16 planes); the results of this step are "
                                    "invalid, later steps use the per-step kernels" +
                                    (h->rearm_wait > 0 ? " (the persistent kernels are tried again after " +
                                                             std::to_string(h->rearm_wait) + " clean steps)"

@@ -82,3 +82,31 @@ def test_aborted_wide_launch_voids_the_step_falls_back_and_is_rearmed(monkeypatc
     assert np.abs(e.get_params() - ref.get_params()).max() < 0.05 * 4e-4
     e.close()
     ref.close()
+
+
+@pytest.mark.parametrize("hook,value,code", [('NASR_WIDE_FAULT_BWD', '2', 'code 1'), ('NASR_WIDE_SCALE_SHIFT', '14', 'code 4')],
+                         ids=['bptt-handoff-timeout', 'dG-beyond-the-fp16-planes'])
+def test_aborted_wide_bptt_voids_the_step(monkeypatch, hook, value, code):
+    """The BPTT kernel's two ways out: a hand-off that times out (NASR_WIDE_FAULT_BWD=s) and a dG * S_row that leaves the
+    range of its fp16 planes (forced here by shifting the per-utterance scale, NASR_WIDE_SCALE_SHIFT).  Either way the
+    step is void - parameters and Adam state untouched - and the same step on the per-step kernels matches an
+    undisturbed engine."""
+    from neuralasr_amd import _lib
+    spec = O.ModelSpec(10, 2048, 1, True, 'concat', 5)
+    B, T = 5, 8
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=4, var_len=True, Lmin=1, Lmax=2)
+    p0 = start_params(spec, 2)
+    e, ref = make_engine(spec, lr=1e-4), make_engine(spec, lr=1e-4)
+    ref.set_recurrence_mode(False)
+    e.set_params(p0)
+    ref.set_params(p0)
+    monkeypatch.setenv(hook, value)
+    with pytest.raises(_lib.NasrError, match='persistent recurrence aborted \\(' + code):
+        e.train_step(feats, seq_len, labels, label_len)
+    monkeypatch.delenv(hook)
+    assert e.recurrence_mode == 'per-step'
+    np.testing.assert_array_equal(e.get_params(), p0)
+    assert e.get_adam_state()[2] == 0
+    assert e.train_step(feats, seq_len, labels, label_len) == pytest.approx(ref.train_step(feats, seq_len, labels, label_len), rel=2e-5)
+    e.close()
+    ref.close()
