@@ -134,7 +134,7 @@ struct WideCtl {               // device words, zeroed before every launch
                                // bit 2 (BPTT): dG left the fp16 range of its planes
   unsigned pad[23];
   unsigned hflag[8 * 32];      // [XCD x][member]: timesteps whose h this workgroup has published
-  unsigned pflag[256 * 32];    // [destination workgroup][source XCD] (8 of 32 words used: one 128-byte line per inbox)
+  unsigned stamps[160];        // diagnostic build (NASR_WSTAMP, tools/widebench): phase cycles of two workgroups' waves
 };
 struct WideGeom {
   int T, Bp, Hp, D, d;

@@ -26,7 +26,22 @@
 #include <utility>
 
 #ifndef NASR_WSTAMP
-#define NASR_WSTAMP 0   // 1: s_memtime deltas per phase, waves of workgroup (0,0) -> WideCtl::pflag tail (tools/widebench)
+#define NASR_WSTAMP 0   // 1: s_memtime deltas per phase -> WideCtl::stamps (tools/widebench)
+#endif
+
+// phase stamps (diagnostic build): every wave of workgroups (0,0) and (7,31) accumulates s_memtime deltas per phase
+#if NASR_WSTAMP
+#define WSTAMP_DECL unsigned long long tl = __builtin_amdgcn_s_memtime(); unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define WMARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += (unsigned)(t_ - tl); tl = t_; } while (0)
+#define WSTAMP_FLUSH                                                                                        \
+  do {                                                                                                      \
+    if (lane == 0 && (me == 0 || me == 255))                                                                \
+      for (int i = 0; i < 10; ++i) ctl->stamps[((me ? 8 : 0) + w) * 10 + i] = tacc[i]; \
+  } while (0)
+#else
+#define WSTAMP_DECL do { } while (0)
+#define WMARK(i) do { } while (0)
+#define WSTAMP_FLUSH do { } while (0)
 #endif
 
 namespace nasr {
@@ -195,13 +210,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
   const unsigned xoff = (unsigned)(rowok ? cb : 0) * (unsigned)DN + (unsigned)(d * N4 + 4 * u);
   auto frame_of = [&](int s) { return (rowok && s < len) ? (d ? len - 1 - s : s) : 0; };
   bool aborted = false;
-#if NASR_WSTAMP
-  unsigned long long tl = __builtin_amdgcn_s_memtime();
-  unsigned tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define WMARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += (unsigned)(t_ - tl); tl = t_; } while (0)
-#else
-#define WMARK(i) do { } while (0)
-#endif
+  WSTAMP_DECL;
 
   for (int s = 0; s < T; ++s) {
     const int par = s & 1;
@@ -248,35 +257,37 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
       WMARK(5);
       wstatic_for<0, MT>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        // the 16 rows' A fragments of all 8 k-tiles, both planes, in one burst of LDS reads (shared by the two tiles)
-        // (three and four M tiles leave no registers for the burst: there the fragments are read per k-tile)
-        constexpr bool BURST = MT <= 2;
-        h8 a0[BURST ? 8 : 1], a1[BURST ? 8 : 1];
-        if constexpr (BURST) {
-#pragma unroll
-          for (int kt = 0; kt < 8; ++kt) {
-            a0[kt] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 0) * 64 + lane]);
-            a1[kt] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 1) * 64 + lane]);
+        // both 16 x 16 tiles of this M tile together; the A fragments of k-tile kt+1 are read while kt multiplies (the
+        // scheduling barriers keep the compiler from hoisting every read to the top, which costs 64 registers per M tile)
+        f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        h8 c0 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 0) * 64 + lane]);
+        h8 c1 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 1) * 64 + lane]);
+        wstatic_for<0, 8>([&](auto ktc) {
+          constexpr int kt = decltype(ktc)::value;
+          h8 n0 = c0, n1 = c1;
+          if constexpr (kt < 7) {
+            n0 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 0) * 64 + lane]);
+            n1 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 1) * 64 + lane]);
           }
-        }
-        wstatic_for<0, 2>([&](auto hc) {
-          constexpr int h2 = decltype(hc)::value;
-          f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-          wstatic_for<0, 8>([&](auto ktc) {
-            constexpr int kt = decltype(ktc)::value;
-            constexpr int ki = BURST ? kt : 0;
-            if constexpr (!BURST) {
-              a0[0] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 0) * 64 + lane]);
-              a1[0] = __builtin_bit_cast(h8, Alds[((kt * MT + m) * 2 + 1) * 64 + lane]);
-            }
-            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ki], ur[kt][h2][0], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ki], ur[kt][h2][1], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ki], ur[kt][h2][0], t, 0, 0, 0);
-          });
-          t *= osc[h2];
-          if (w != x) st16_sc1(pdst + (m * 2 + h2) * 256, t);
-          else Plds[((x * MT + m) * 2 + h2) * 64 + lane] = t;
+          t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][0][0], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][1][0], t1, 0, 0, 0);
+          t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][0][1], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][1][1], t1, 0, 0, 0);
+          t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][0][0], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][1][0], t1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          c0 = n0;
+          c1 = n1;
         });
+        t0 *= osc[0];
+        t1 *= osc[1];
+        if (w != x) {
+          st16_sc1(pdst + (m * 2 + 0) * 256, t0);
+          st16_sc1(pdst + (m * 2 + 1) * 256, t1);
+        } else {
+          Plds[((x * MT + m) * 2 + 0) * 64 + lane] = t0;
+          Plds[((x * MT + m) * 2 + 1) * 64 + lane] = t1;
+        }
       });
       WMARK(4);
       // 4. the 7 partial sums of the own units that other XCDs computed: wave w fetches source slice w.  No flag: the
@@ -383,11 +394,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
     if (tid == 0) hflag[nb] = (unsigned)s + 1u;
     if (abort_word) { aborted = true; break; }
   }
-#if NASR_WSTAMP
-  if (lane == 0 && (me == 0 || me == 255))
-    for (int i = 0; i < 10; ++i) ctl->pflag[256 * 32 - 256 + ((me ? 8 : 0) + w) * 10 + i] = tacc[i];
-#endif
-#undef WMARK
+  WSTAMP_FLUSH;
   if (aborted && tid == 0) wide_raise(ctl, sticky, gm.fault, 1u);
 }
 
@@ -398,7 +405,8 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
 //      sentinel-polled inboxes as in the forward kernel, one copy per reader;
 //   2. partial dh of the XCD's 256 units over this workgroup's 256 gate columns: A = dG planes, B = U^T planes under
 //      per-unit (row of U) scales, three products; wave w owns units [32w, 32w+32) of the slice = members 4w .. 4w+3;
-//   3. XCD-local reduce-scatter through the L2: 32 sources x [rows x 8 units] per workgroup, flag per (source, wave);
+//   3. XCD-local reduce-scatter through the L2: 32 sources x [rows x 8 units] per workgroup, sentinel-polled like the inboxes
+//      (every (destination, source) block has one reader);
 //   4. cell backward of the 8 own units (dc in a register for all T), dG to HBM (frame-indexed, for the weight-gradient
 //      GEMMs) and, as planes, to the 8 inboxes.
 // A dG * S_row beyond the fp16 range raises error bit 2: the launch drains and the step is void (the caller repeats it on
@@ -526,7 +534,6 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
   float* sinv = reinterpret_cast<float*>(wlds + L::SINV);     // 1 / S of every utterance row (read back per tile)
   if (tid < ROWS) sinv[tid] = tid < Bp ? 1.f / srow[tid] : 1.f;
   __syncthreads();
-  gu32* bflag = (gu32*)ctl->pflag;              // [(x*32 + src)*32 + wave]
 
   // ---- cell threads
   const bool cell = tid < 8 * ROWS;
@@ -537,11 +544,13 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
   const float sb = rowok ? srow[cb] : 1.f;
   float dc = 0.f;
   bool aborted = false;
+  WSTAMP_DECL;
   const f32x4 sent = __builtin_bit_cast(f32x4, (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu});
 
   for (int k = 0; k < T; ++k) {
     const int s = T - 1 - k, par = k & 1;
     bool ok = true;
+    WMARK(0);
     // per-frame operands of the cell backward: in flight during the gather / product phases.  Unconditional loads
     // (a masked cell reads frame 0 of its row and is zeroed below).
     const bool valid = rowok && s < len;
@@ -588,6 +597,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
           if (__all(all)) { ok = true; break; }
         }
         if (s == gm.inject && me == 0) ok = false;
+        WMARK(1);
         if (ok) {
 #pragma unroll
           for (int m = 0; m < MT; ++m)
@@ -601,10 +611,15 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
         }
       }
     }
+    WMARK(2);
     __syncthreads();                                        // #1: dG of step k-1 is in LDS (all 8 column groups)
+    WMARK(3);
     if (k > 0 && !info[2]) {
       // 2. partial dh of units [32w, 32w+32) of the slice; each 16 x 16 tile goes to the XCD's exchange buffer at once
       f32x4* pdst = px + (((size_t)(par * 8 + x) * 32) * 32 + nb) * PU;        // + dest * 32 * PU
+      // (the sentinels this wave wrote as a READER one step ago are acknowledged before it writes as a source again: whoever
+      //  sees the partial sums below and later refills a block this wave reset finds the reset in the L2 already)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wstatic_for<0, MT>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         // both 16 x 16 tiles of this M tile together; the A fragments of k-tile kt+1 are read while kt multiplies (the
@@ -638,30 +653,46 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
         pd[0] = t0;
         pd[(size_t)2 * 32 * PU] = t1;
       });
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // acknowledged before the flag goes out
-      if (lane == 0) bflag[me * 32 + w] = (unsigned)k;
-      load_cell();                                           // in flight under the flag poll and the gather below
-      // 3. the 32 partial sums of the own 8 units: wave w fetches sources 4w .. 4w+3 (each from the wave that owns this
-      // workgroup's units: nb >> 2)
-      ok = wpoll_ge(bflag + (x * 32 + 4 * w + (lane & 3)) * 32 + (nb >> 2), lane < 4, (unsigned)k);
-      if (ok) {
-        const f32x4* src = px + (((size_t)(par * 8 + x) * 32 + nb) * 32 + 4 * w) * PU;
+      WMARK(4);
+      load_cell();                                           // in flight under the gather below
+      WMARK(5);
+      // 3. the 32 partial sums of the own 8 units: wave w fetches sources 4w .. 4w+3.  No flag, as across the XCDs: every
+      // (destination, source) block has ONE reader, so its words are polled against the sentinel and reset after the read
+      {
+        f32x4* src = px + (((size_t)(par * 8 + x) * 32 + nb) * 32 + 4 * w) * PU;
         constexpr int NL = (4 * PU + 63) / 64;               // 16-byte loads per lane for 4 sources
         u32x4 v[NL];
+        ok = false;
+        for (unsigned n = 0; n < WIDE_SPIN; ++n) {
+          bool all = true;
 #pragma unroll
-        for (int j = 0; j < NL; ++j)
-          if (lane + 64 * j < 4 * PU) v[j] = ld16_sc1(src + lane + 64 * j);
+          for (int j = 0; j < NL; ++j)
+            if (lane + 64 * j < 4 * PU) v[j] = ld16_sc1(src + lane + 64 * j);
 #pragma unroll
-        for (int j = 0; j < NL; ++j)
-          if (lane + 64 * j < 4 * PU) wait_vm0(v[j]);
+          for (int j = 0; j < NL; ++j)
+            if (lane + 64 * j < 4 * PU) {
+              wait_vm0(v[j]);
+              const u32x4 q = v[j];
+              all = all && q.x != 0xffffffffu && q.y != 0xffffffffu && q.z != 0xffffffffu && q.w != 0xffffffffu;
+            }
+          if (__all(all)) { ok = true; break; }
+        }
+        WMARK(6);
+        if (ok) {
 #pragma unroll
-        for (int j = 0; j < NL; ++j)
-          if (lane + 64 * j < 4 * PU) PBlds[4 * w * PU + lane + 64 * j] = __builtin_bit_cast(f32x4, v[j]);
-      } else {
-        info[2] = 1;
+          for (int j = 0; j < NL; ++j)
+            if (lane + 64 * j < 4 * PU) {
+              PBlds[4 * w * PU + lane + 64 * j] = __builtin_bit_cast(f32x4, v[j]);
+              src[lane + 64 * j] = sent;                     // plain store: this XCD's L2
+            }
+        } else {
+          info[2] = 1;
+        }
       }
     }
+    WMARK(7);
     __syncthreads();                                        // #2: the 32 partial sums are in LDS
+    WMARK(8);
     const unsigned abort_word = info[2];
     // 4. cell backward of (row cb, unit ci)
     if (cell) {
@@ -720,8 +751,10 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
         for (int p = 0; p < 2; ++p)
           st16_sc1(dst + (m * 2 + p) * 64, __builtin_bit_cast(f32x4, Alds[((x * MT + m) * 2 + p) * 64 + lane]));
     }
+    WMARK(9);
     if (abort_word || aborted) { aborted = true; break; }
   }
+  WSTAMP_FLUSH;
   if (aborted && tid == 0) wide_raise(ctl, sticky, gm.fault, 1u);
 }
 
@@ -762,6 +795,7 @@ void launch_lstm_wide_bwd(const LstmDims& dm, int d, const void* Uwb, const floa
                           float* inbox, void* px, WideCtl* ctl, unsigned* sticky, float* fault, hipStream_t st) {
   (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
   (void)hipMemsetAsync(inbox, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
+  (void)hipMemsetAsync(px, 0xff, wide_px_bytes(dm.Bp), st);
   WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, fault};
   if (const char* e = getenv("NASR_WIDE_FAULT_BWD")) gm.inject = atoi(e);
   const int MT = dm.Bp / 16;

@@ -107,7 +107,7 @@ int main(int argc, char** argv) {
   if (getenv("WIDE_STAMPS")) {
     std::vector<unsigned> hc(sizeof(WideCtl) / 4);
     CK(hipMemcpy(hc.data(), ctl, sizeof(WideCtl), hipMemcpyDeviceToHost));
-    const unsigned* st_ = hc.data() + (offsetof(WideCtl, pflag) / 4) + 256 * 32 - 256;
+    const unsigned* st_ = hc.data() + (offsetof(WideCtl, stamps) / 4);
     const char* names[10] = {"loop-top", "h-poll", "h-load+lds", "barrier1", "mfma", "part-store+ack", "part-poll", "part-load+lds", "barrier2", "cell..barrier3"};
     printf("cycles per step (100 MHz s_memtime ticks x 24 ~ core cycles at 2.4 GHz):\n");
     for (int i = 0; i < 10; ++i) {
@@ -236,6 +236,18 @@ int main(int argc, char** argv) {
       }
       CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
       CK(hipEventElapsedTime(&msD, a, b));
+    }
+    if (getenv("WIDE_STAMPS")) {
+      std::vector<unsigned> hc(sizeof(WideCtl) / 4);
+      CK(hipMemcpy(hc.data(), ctl, sizeof(WideCtl), hipMemcpyDeviceToHost));
+      const unsigned* st_ = hc.data() + (offsetof(WideCtl, stamps) / 4);
+      const char* names[10] = {"loop-top", "dG-poll+load", "dG-lds", "barrier1", "mfma+stores", "ack+flag", "px-poll", "px-load+lds", "barrier2", "cell..publish"};
+      printf("BPTT cycles per step:\n");
+      for (int i = 0; i < 10; ++i) {
+        printf("  %-16s", names[i]);
+        for (int wv = 0; wv < 16; ++wv) printf(" %6.1f", st_[wv * 10 + i] / (double)T);
+        printf("\n");
+      }
     }
     printf("BPTT T %d B %d: per-step kernels %.3f ms (%.2f us/step), wide persistent %.3f ms (%.2f us per direction-step)\n", T, B,
            msC, msC * 1e3 / T, msD, msD * 1e3 / (2 * T));
