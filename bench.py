@@ -477,13 +477,16 @@ def main():
         # T x the per-timestep figure of SURVEY.md §8d (which prices the recurrent matrix once per timestep; the
         # persistent kernels keep it in registers, so the PMC traffic sits far below this figure)
         persistent = eng.recurrence_mode == 'persistent'
-        spl = T if persistent else 1
+        wide = eng.recurrence_mode == 'wide-persistent'     # one launch per DIRECTION and pass (lstm_wide.hip)
+        spl = T if (persistent or wide) else 1
+        dpl = spec.dirs if wide else 1                      # launches that share one timestep's algorithmic bytes
         fwd_us = phases['rec_fwd_ms'] * 1e3 / max(phases['rec_fwd_launches'], 1)
         bwd_us = phases['rec_bwd_ms'] * 1e3 / max(phases['rec_bwd_launches'], 1)
         dom_bwd = phases['rec_bwd_ms'] >= phases['rec_fwd_ms']
-        k_bytes, k_us = (bb * spl, bwd_us) if dom_bwd else (fb * spl, fwd_us)
+        k_bytes, k_us = (bb * spl / dpl, bwd_us) if dom_bwd else (fb * spl / dpl, fwd_us)
         achieved = k_bytes / (k_us * 1e-6) / 1e9
         kname = ('lstm_persist_bwd_kernel' if dom_bwd else 'lstm_persist_fwd_kernel') if persistent else \
+                ('lstm_wide_bwd_kernel' if dom_bwd else 'lstm_wide_fwd_kernel') if wide else \
                 ('lstm_bwd_step_kernel' if dom_bwd else 'lstm_fwd_step_kernel')
         # PMC figures of the same command (separate --pmc passes, tools/pmc_summary.py); the files are named in the line
         pj, pmc_file = load_profile('pmc')
@@ -496,6 +499,11 @@ def main():
         macs = spec.dirs * 16 * 512 * 2048 if spec.hidden <= 512 else None      # padded Hp = 512, 16 utterance rows
         floor_fwd = macs * 3 / 1024 / (1024 * 2.4e3) * 8 if macs else None        # us
         floor_bwd = macs / 256 / (1024 * 2.4e3) * 8 if macs else None
+        if wide:
+            # one DIRECTION's timestep: Bp x 2048 x 8192 MACs as 3 fp16 products on 16x16x32 MFMAs (8192 MACs, 16 cycles),
+            # forward and BPTT alike
+            bp = (B + 15) // 16 * 16
+            floor_fwd = floor_bwd = bp * 2048 * 8192 * 3 / 8192 / 1024 * 16 / 2.4e3
         out = {
             'metric': f'audio-frames/sec (fwd+bwd+CTC+Adam) at batch {B} per GPU',
             'value': total_frames * args.steps / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
@@ -527,10 +535,14 @@ def main():
                                      'mfma_floor_us': floor_bwd if dom_bwd else floor_fwd,
                                      'fwd_step_us': fwd_us / spl, 'fwd_mfma_floor_us': floor_fwd,
                                      'bwd_step_us': bwd_us / spl, 'bwd_mfma_floor_us': floor_bwd,
-                                     'phase_cycles': (sj or {}).get(wkey if wkey in (sj or {}) else 'bilstm3x500'),
-                                     'note': 'bound = per-timestep dependent chain inside one XCD (flag/payload hand-off '
-                                             'through L2, MFMA phase, cell update), not HBM; phase_cycles = in-kernel '
-                                             's_memtime stamps of wave 0 (tools/persistbench, NASR_PSTAMP build)'},
+                                     'phase_cycles': (sj or {}).get(wkey if (wkey in (sj or {}) or wide) else 'bilstm3x500'),
+                                     'note': ('bound = per-timestep dependent chain across the chip (partial sums / dG '
+                                              'planes across the XCDs, h / partial dh through the XCD L2, MFMA phase, cell '
+                                              'update), not HBM; step_us is per DIRECTION-step (one launch per direction)'
+                                              if wide else
+                                              'bound = per-timestep dependent chain inside one XCD (flag/payload hand-off '
+                                              'through L2, MFMA phase, cell update), not HBM; phase_cycles = in-kernel '
+                                              's_memtime stamps of wave 0 (tools/persistbench, NASR_PSTAMP build)')},
                          'sources': {'traffic_mfma_busy': pmc_file, 'phase_cycles': stamp_file,
                                      'us_per_launch': 'live HIP events on the engine stream (nasr_get_phase_times)'}},
             'roofline_step': {'bound': 'hbm', 'bytes_alg': A + W + R, 'bytes_compulsory': A + W,

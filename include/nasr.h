@@ -255,8 +255,8 @@ int nasr_set_graph_mode(nasr_handle h, int enabled); /* capture the per-timestep
 /* How the recurrence of tf.nn.(bidirectional_)dynamic_rnn (networks/bilstm_ctc_net.py:24-28,
  * networks/lstm_ctc_net.py:22-23) runs: 1 = one persistent launch per layer pass (one XCD per direction and
  * utterance slice, recurrent matrix resident in registers), 2 = a layer of 2048 cells (networks/deepspeech.py:70-103):
- * one persistent launch per DIRECTION for the forward recurrence (the matrix resident in the registers of all 256 CUs),
- * BPTT one launch per timestep, 0 = one launch per timestep.  nasr_set_recurrence_mode(0)
+ * one persistent launch per DIRECTION and pass (the matrix resident in the registers of all 256 CUs as fp16 planes),
+ * 0 = one launch per timestep.  nasr_set_recurrence_mode(0)
  * forces the per-step kernels; (1) asks for the persistent ones again and returns NASR_ERR_STATE where the device or
  * the hidden size does not support them.  A persistent launch wants every CU of the device for itself: if another
  * process or handle keeps CUs busy for longer than its bounded spins (~0.5 s), the launch gives up, the step is void

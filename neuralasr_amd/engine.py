@@ -413,9 +413,9 @@ class Engine:
 
     @property
     def recurrence_mode(self):
-        """'persistent' (one launch per layer pass, lstm_persist.hip), 'wide-forward' (Hp = 2048: one persistent launch per
-        direction for the forward recurrence, lstm_wide.hip; BPTT per step) or 'per-step' (lstm.hip)."""
-        return ('per-step', 'persistent', 'wide-forward')[int(self.lib.nasr_get_recurrence_mode(self.h))]
+        """'persistent' (one launch per layer pass, lstm_persist.hip), 'wide-persistent' (Hp = 2048: one persistent launch per
+        direction and pass, lstm_wide.hip) or 'per-step' (lstm.hip)."""
+        return ('per-step', 'persistent', 'wide-persistent')[int(self.lib.nasr_get_recurrence_mode(self.h))]
 
     def persist_stats(self):
         """(aborts, re-arms) of the persistent recurrence on this handle (include/nasr.h, nasr_get_persist_stats)."""

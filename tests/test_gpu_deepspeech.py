@@ -121,8 +121,8 @@ def test_deepspeech_training_step_matches_oracle_adam():
 
 def test_reference_shape_constructs_and_steps():
     """networks/deepspeech.py at its own sizes (n_hidden 2048, BiLSTM 2048, 26-MFCC x 21 context), a short batch:
-    the wide persistent forward kernel (lstm_wide.hip: one launch per direction) + the per-step BPTT serve Hp = 2048; loss
-    finite and decreasing, and the same steps on the per-step forward kernels give the same losses and parameters."""
+    the wide persistent kernels (lstm_wide.hip: one launch per direction and pass) serve Hp = 2048; loss finite and
+    decreasing, and the same steps on the per-step kernels give the same losses and parameters."""
     from neuralasr_amd.networks.deepspeech import DeepSpeech
     spec = O.ModelSpec(546, DeepSpeech.n_cell_dim, 1, True, 'concat', 29, pre=DeepSpeech.pre_widths(), post=DeepSpeech.n_hidden,
                        relu_clip=DeepSpeech.relu_clip, dropout=DeepSpeech.dropout)
@@ -130,9 +130,9 @@ def test_reference_shape_constructs_and_steps():
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1, Lmin=2, Lmax=4)
     rs = np.random.RandomState(0)
     runs = {}
-    for mode in ('wide-forward', 'per-step'):
+    for mode in ('wide-persistent', 'per-step'):
         e = make_engine(spec, lr=1e-4)
-        assert e.recurrence_mode == 'wide-forward'
+        assert e.recurrence_mode == 'wide-persistent'
         if mode == 'per-step':
             e.set_recurrence_mode(False)
         assert e.recurrence_mode == mode
@@ -143,8 +143,8 @@ def test_reference_shape_constructs_and_steps():
         assert np.isfinite(losses).all() and losses[2] < losses[0]
         runs[mode] = (losses, e.get_params())
         e.close()
-    np.testing.assert_allclose(runs['wide-forward'][0], runs['per-step'][0], rtol=2e-5)
-    d = runs['wide-forward'][1] - runs['per-step'][1]
+    np.testing.assert_allclose(runs['wide-persistent'][0], runs['per-step'][0], rtol=2e-5)
+    d = runs['wide-persistent'][1] - runs['per-step'][1]
     # Adam's first steps move every weight by ~lr whatever its gradient: compare against that step size
     assert np.abs(d).max() < 0.05 * 3e-4, np.abs(d).max()
 

@@ -34,9 +34,9 @@ def test_wide_forward_equals_the_per_step_kernels(bi, B, T):
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=B + T, var_len=True, Lmin=1, Lmax=2)
     p0 = start_params(spec, 1)
     out = {}
-    for mode in ('wide-forward', 'per-step'):
+    for mode in ('wide-persistent', 'per-step'):
         e = make_engine(spec)
-        assert e.recurrence_mode == 'wide-forward'
+        assert e.recurrence_mode == 'wide-persistent'
         if mode == 'per-step':
             e.set_recurrence_mode(False)
         assert e.recurrence_mode == mode
@@ -45,7 +45,7 @@ def test_wide_forward_equals_the_per_step_kernels(bi, B, T):
         loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
         out[mode] = (logits, loss, grads)
         e.close()
-    a, b = out['wide-forward'], out['per-step']
+    a, b = out['wide-persistent'], out['per-step']
     np.testing.assert_allclose(a[0], b[0], atol=2e-5)
     assert a[1] == pytest.approx(b[1], rel=2e-6)
     assert np.linalg.norm(a[2] - b[2]) <= 2e-5 * np.linalg.norm(b[2])
@@ -65,7 +65,7 @@ def test_aborted_wide_launch_voids_the_step_falls_back_and_is_rearmed(monkeypatc
     ref.set_recurrence_mode(False)
     e.set_params(p0)
     ref.set_params(p0)
-    assert e.recurrence_mode == 'wide-forward' and e.persist_stats() == (0, 0)
+    assert e.recurrence_mode == 'wide-persistent' and e.persist_stats() == (0, 0)
     monkeypatch.setenv('NASR_WIDE_FAULT', '3')
     with pytest.raises(_lib.NasrError, match='persistent recurrence aborted'):
         e.train_step(feats, seq_len, labels, label_len)
@@ -73,7 +73,7 @@ def test_aborted_wide_launch_voids_the_step_falls_back_and_is_rearmed(monkeypatc
     assert e.recurrence_mode == 'per-step' and e.persist_stats() == (1, 0)
     np.testing.assert_array_equal(e.get_params(), p0)                 # the void step changed nothing
     assert e.get_adam_state()[2] == 0
-    for want in ('per-step', 'per-step', 'wide-forward', 'wide-forward'):
+    for want in ('per-step', 'per-step', 'wide-persistent', 'wide-persistent'):
         loss = e.train_step(feats, seq_len, labels, label_len)
         assert e.recurrence_mode == want
         assert loss == pytest.approx(ref.train_step(feats, seq_len, labels, label_len), rel=2e-5)
