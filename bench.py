@@ -557,6 +557,18 @@ def main():
                                     'note': 'the next batch staged through pinned memory on the copy stream while the '
                                             'step runs (nasr_stage_batch + nasr_commit_batch)'}},
         }
+        if wide:
+            # The wide kernels keep the recurrent matrix resident for the whole launch, so SURVEY §8d's per-timestep bytes
+            # (which re-price it every step) exceed what any memory system could deliver in the launch's time: quoted as
+            # `hbm_algorithmic_frac`, not as the bound.  What the launch is priced against is its MFMA work: one direction's
+            # T timesteps of Bp x Hp x 4Hp MACs as three fp16 products, against the dense fp16 matrix peak.
+            rl = out['roofline']
+            bp = (B + 15) // 16 * 16
+            tf = 2.0 * bp * 2048 * 8192 * 3 * T / 1e12
+            rl.update({'bound': 'mfma', 'hbm_algorithmic_frac': rl['frac'], 'achieved': tf / (k_us * 1e-6), 'peak': 2500.0,
+                       'unit': 'TFLOP/s', 'frac': tf / (k_us * 1e-6) / 2500.0, 'mfma_products_per_fp32_product': 3,
+                       'note': 'one direction per launch; the dependent chain of a timestep (see latency) bounds it, the '
+                               'MFMA floor is 1.28 us of it'})
         # (ii) of SURVEY.md §8d: the dense contractions (everything hoisted out of the time loop).  They run as THREE fp16
         # MFMA products per fp32 product, so the instruction stream is priced against the dense fp16 matrix peak with the
         # product count in; the fp32-equivalent rate is given beside it.  The phases include the plane / scale passes.

@@ -139,6 +139,7 @@ struct WideCtl {               // device words, zeroed before every launch
 struct WideGeom {
   int T, Bp, Hp, D, d;
   int inject;                  // test hook (NASR_WIDE_FAULT=s): workgroup (0,0) treats the poll of step s as timed out
+  int scale_shift;             // test hook (NASR_WIDE_SCALE_SHIFT): added to the exponent of the BPTT's dG scales
   float* fault;
 };
 bool wide_supported(int Hp, int Bp);
@@ -154,7 +155,7 @@ void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float
                           float* fault, float forget_bias, hipStream_t st);
 
 // BPTT of the same layer: Uwb = the backward image (U^T fragments under per-row scales rs [Hp]; rinv = 1 / rs), srow [D][Bp]
-// = power-of-two scale of dG per (direction, utterance) from launch_wide_row_scales; inbox = the forward kernel's partial-sum
+// = largest |dOut| per (direction, utterance) from launch_wide_row_scales (the kernel derives its power-of-two dG scale); inbox = the forward kernel's partial-sum
 // buffer (wide_part_bytes), px = wide_px_bytes
 size_t wide_px_bytes(int Bp);
 void launch_repack_wide_bwd(const float* U, const float* rs, void* Uwb, int Hp, hipStream_t st);

@@ -446,17 +446,25 @@ void launch_repack_wide_bwd(const float* U, const float* rs, void* Uwb, int Hp, 
   hipLaunchKernelGGL(repack_wide_bwd_kernel, dim3(2048), dim3(256), 0, st, U, rs, reinterpret_cast<u32x4*>(Uwb), Hp);
 }
 
-// srow [D][Bp]: power-of-two scale per (direction, utterance) that brings the largest |dOut| of that utterance's frames into
-// [2^5, 2^6) (1 where the utterance has no gradient): dG = O(dOut) then has 2^10 of headroom in fp16.  One block per (b, d).
-__global__ __launch_bounds__(256) void wide_row_scale_kernel(const float* __restrict__ dout, const int* __restrict__ seq_len,
-                                                             float* __restrict__ srow, int T, int Bp, int Hp, int D, int shift) {
+// smax [D][Bp] (zeroed by the launcher): bits of the largest |dOut| over the frames and units of every (direction, utterance);
+// non-negative floats order like their bit patterns, so the partial maxima of the (utterance, direction, time chunk) blocks
+// meet in an atomicMax.  The BPTT kernel turns it into the power-of-two scale S that brings that maximum into [2^5, 2^6)
+// (1 where the utterance has no gradient): dG = O(dOut) then has 2^10 of headroom in the fp16 planes.
+constexpr int WIDE_SCALE_CHUNK = 16;   // frames per block
+__global__ __launch_bounds__(256) void wide_row_max_kernel(const float* __restrict__ dout, const int* __restrict__ seq_len,
+                                                           unsigned* __restrict__ smax, int T, int Bp, int Hp, int D) {
   __shared__ float red[256];
   const int b = blockIdx.x, d = blockIdx.y, DH = D * Hp;
   const int len = seq_len[b] < T ? seq_len[b] : T;
+  const int t0 = blockIdx.z * WIDE_SCALE_CHUNK, t1 = t0 + WIDE_SCALE_CHUNK < len ? t0 + WIDE_SCALE_CHUNK : len;
+  if (t0 >= len) return;
   float m = 0.f;
-  for (int t = 0; t < len; ++t) {
-    const float* row = dout + ((size_t)t * Bp + b) * DH + d * Hp;
-    for (int j = threadIdx.x; j < Hp; j += 256) m = fmaxf(m, fabsf(row[j]));
+  for (int t = t0; t < t1; ++t) {
+    const float4* row = reinterpret_cast<const float4*>(dout + ((size_t)t * Bp + b) * DH + d * Hp);
+    for (int j = threadIdx.x; j < Hp / 4; j += 256) {
+      const float4 v = row[j];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
   }
   red[threadIdx.x] = m;
   __syncthreads();
@@ -464,16 +472,15 @@ __global__ __launch_bounds__(256) void wide_row_scale_kernel(const float* __rest
     if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const float mx = red[0];
-    float sc = 1.f;
-    if (mx > 0.f && mx < 3e38f) {
-      int e;
-      (void)frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
-      sc = ldexpf(1.f, 6 - e + shift);      // mx * sc in [2^5, 2^6) (shift: test hook NASR_WIDE_SCALE_SHIFT)
-    }
-    srow[d * Bp + b] = sc;
-  }
+  if (threadIdx.x == 0 && red[0] > 0.f) atomicMax(&smax[d * Bp + b], __float_as_uint(red[0]));
+}
+
+__device__ __forceinline__ float wide_scale_of(unsigned maxbits, int shift) {
+  const float mx = __uint_as_float(maxbits);
+  if (!(mx > 0.f && mx < 3e38f)) return 1.f;
+  int e;
+  (void)frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 6 - e + shift);    // mx * S in [2^5, 2^6) (shift: test hook NASR_WIDE_SCALE_SHIFT)
 }
 
 // LDS map (16-byte units): A [8 kt][MT][2 p][64] | PB [32 src][32*MT] | sinv [16*MT floats] | info
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
     u32x4* inbox,                       // [2 parity][256 dest][8 src][MT][2 plane][64 lane]: dG planes in A-fragment order
     f32x4* px,                          // [2 parity][8 x][32 dest][32 src][32*MT]: partial dh, [m][unit 8][q 4] x 4 rows
     WideCtl* ctl, unsigned* sticky, WideGeom gm, const float* __restrict__ rinv,   // [Hp] 1 / row scale of U
-    const float* __restrict__ srow) {   // [Bp] dG scale of this direction
+    const unsigned* __restrict__ smax) {   // [Bp] bits of max |dOut| per utterance of this direction (wide_row_max_kernel)
   extern __shared__ __attribute__((aligned(16))) u32x4 wlds[];
   using L = WideLdsB<MT>;
   constexpr int ROWS = 16 * MT, PU = 32 * MT;     // PU: 16-byte units of one [rows x 8 units] partial block
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) oun[nt] = rinv[KS * x + 32 * w + 16 * nt + (lane & 15)];
   float* sinv = reinterpret_cast<float*>(wlds + L::SINV);     // 1 / S of every utterance row (read back per tile)
-  if (tid < ROWS) sinv[tid] = tid < Bp ? 1.f / srow[tid] : 1.f;
+  if (tid < ROWS) sinv[tid] = tid < Bp ? 1.f / wide_scale_of(smax[tid], gm.scale_shift) : 1.f;
   __syncthreads();
 
   // ---- cell threads
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
   const int u = KS * x + 8 * nb + ci;
   const bool rowok = cell && cb < Bp;
   const int len = rowok ? seq_len[cb] : 0;
-  const float sb = rowok ? srow[cb] : 1.f;
+  const float sb = rowok ? wide_scale_of(smax[cb], gm.scale_shift) : 1.f;
   float dc = 0.f;
   bool aborted = false;
   WSTAMP_DECL;
@@ -784,10 +791,9 @@ hipError_t wide_prepare() {
 size_t wide_px_bytes(int Bp) { return (size_t)2 * 8 * 32 * 32 * (32 * (Bp / 16)) * 16; }
 
 void launch_wide_row_scales(const LstmDims& dm, const float* dout, const int* seq_len, float* srow, hipStream_t st) {
-  int shift = 0;
-  if (const char* e = getenv("NASR_WIDE_SCALE_SHIFT")) shift = atoi(e);   // test hook: > 10 drives dG * S out of the fp16 range
-  hipLaunchKernelGGL(wide_row_scale_kernel, dim3(dm.Bp, dm.D), dim3(256), 0, st, dout, seq_len, srow, dm.T, dm.Bp, dm.Hp, dm.D,
-                     shift);
+  (void)hipMemsetAsync(srow, 0, (size_t)dm.D * dm.Bp * 4, st);
+  hipLaunchKernelGGL(wide_row_max_kernel, dim3(dm.Bp, dm.D, (dm.T + WIDE_SCALE_CHUNK - 1) / WIDE_SCALE_CHUNK), dim3(256), 0, st, dout,
+                     seq_len, reinterpret_cast<unsigned*>(srow), dm.T, dm.Bp, dm.Hp, dm.D);
 }
 
 void launch_lstm_wide_bwd(const LstmDims& dm, int d, const void* Uwb, const float* rinv, const float* srow,
@@ -796,13 +802,15 @@ void launch_lstm_wide_bwd(const LstmDims& dm, int d, const void* Uwb, const floa
   (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
   (void)hipMemsetAsync(inbox, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
   (void)hipMemsetAsync(px, 0xff, wide_px_bytes(dm.Bp), st);
-  WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, fault};
+  WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, 0, fault};
   if (const char* e = getenv("NASR_WIDE_FAULT_BWD")) gm.inject = atoi(e);
+  if (const char* e = getenv("NASR_WIDE_SCALE_SHIFT")) gm.scale_shift = atoi(e);   // test hook: > 10 drives dG * S out of the fp16 range
   const int MT = dm.Bp / 16;
 #define NASR_WIDE(MTV)                                                                                               \
   hipLaunchKernelGGL((lstm_wide_bwd_kernel<MTV>), dim3(256), dim3(512), WideLdsB<MTV>::END * 16, st,                 \
                      reinterpret_cast<const u32x4*>(Uwb), gates, dgbuf, cbuf, dout, seq_len,                           \
-                     reinterpret_cast<u32x4*>(inbox), reinterpret_cast<f32x4*>(px), ctl, sticky, gm, rinv, srow + (size_t)d * dm.Bp)
+                     reinterpret_cast<u32x4*>(inbox), reinterpret_cast<f32x4*>(px), ctl, sticky, gm, rinv,                    \
+                     reinterpret_cast<const unsigned*>(srow) + (size_t)d * dm.Bp)
   switch (MT) {
     case 1: NASR_WIDE(1); break;
     case 2: NASR_WIDE(2); break;
@@ -817,7 +825,7 @@ void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float
                           float* fault, float forget_bias, hipStream_t st) {
   (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
   (void)hipMemsetAsync(part, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
-  WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, fault};
+  WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, 0, fault};
   if (const char* e = getenv("NASR_WIDE_FAULT")) gm.inject = atoi(e);
   const int MT = dm.Bp / 16;
 #define NASR_WIDE(MTV)                                                                                               \
