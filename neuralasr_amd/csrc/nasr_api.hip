@@ -1559,7 +1559,7 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     // is [head | dense stages | layer 0 | ... | layer L-1 | W | b] and backward() finishes W, b first, then the layers
     // from the top down, then the dense stages in front of the stack.  Bucket 0 = layer L-1 + W + b, then one bucket
     // per layer down to layer 1, and a last one with everything in front of layer 1 INCLUDING the fault word, which
-    // any launch of the step may still raise.  A one-layer net has a single bucket.
+    // any launch of the step may still raise.  A one-layer net has a single bucket, unless dense stages precede it.
     h->bucket_of_layer.assign(h->L, -1);
     if (h->L > 1 && h->L <= MAX_BUCKETS) {
       for (int l = h->L - 1; l >= 1; --l) {
@@ -1568,6 +1568,12 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
         h->buckets.push_back({GRAD_HEAD + lo, hi - lo});
       }
       h->buckets.push_back({0, GRAD_HEAD + h->off_wx[1]});
+    } else if (h->L == 1 && h->npre > 0) {
+      // a DeepSpeech-shaped net: the (Bi)LSTM's gradients (4/5 of the parameters at the reference's widths) + W + b are
+      // complete before the backward pass of the dense stages in front of it, which then hides their all-reduce
+      h->bucket_of_layer[0] = 0;
+      h->buckets.push_back({GRAD_HEAD + h->off_wx[0], h->np_int - h->off_wx[0]});
+      h->buckets.push_back({0, GRAD_HEAD + h->off_wx[0]});
     } else {
       h->buckets.push_back({0, GRAD_HEAD + h->np_int});
     }

@@ -223,3 +223,17 @@ def test_reference_widths_match_the_oracle():
     g_o = O.flatten(grads_o)
     assert np.linalg.norm(grads - g_o) <= 1e-2 * np.linalg.norm(g_o)
     e.close()
+
+
+def test_lstm_gradients_form_a_bucket_of_their_own():
+    """include/nasr.h "Overlapping the exchange": a DeepSpeech-shaped net finishes the (Bi)LSTM's gradients + W + b before
+    the backward pass of the dense stages in front of it, so they are bucket 0 (released after the layer's weight
+    gradients) and the dense stages + the fault word the last bucket; the two tile the device buffer."""
+    spec = CASES[1][0]
+    e = make_engine(spec)
+    buckets = e.grad_buckets()
+    assert len(buckets) == 2 and buckets[-1][0] == 0 and buckets[0][0] == buckets[-1][1]
+    assert sum(c for _, c in buckets) == e.grad_device_ptr()[1]
+    H, D = spec.hidden, 2
+    assert buckets[0][1] >= (spec.pre[-1] + H) * 4 * H * D          # at least the layer's kernels
+    e.close()
