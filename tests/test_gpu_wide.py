@@ -110,3 +110,28 @@ def test_aborted_wide_bptt_voids_the_step(monkeypatch, hook, value, code):
     assert e.train_step(feats, seq_len, labels, label_len) == pytest.approx(ref.train_step(feats, seq_len, labels, label_len), rel=2e-5)
     e.close()
     ref.close()
+
+
+def test_full_length_pass_agrees_with_the_per_step_kernels():
+    """BASELINE.json configs[3]'s recurrence at its own size (B 32, T 500, bidirectional, ragged lengths): 2 x 500 dependent
+    timesteps through both wide kernels against 2 x 1000 per-step launches - loss, logits and every gradient tensor."""
+    spec = O.ModelSpec(26, 2048, 1, True, 'concat', 29)
+    B, T = 32, 500
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=11, var_len=True, Lmin=20, Lmax=60)
+    p0 = start_params(spec, 5)
+    out = {}
+    for mode in ('wide-persistent', 'per-step'):
+        e = make_engine(spec)
+        if mode == 'per-step':
+            e.set_recurrence_mode(False)
+        assert e.recurrence_mode == mode
+        e.set_params(p0)
+        loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+        out[mode] = (loss, nll, grads, e.tensors())
+        e.close()
+    a, b = out['wide-persistent'], out['per-step']
+    assert np.isfinite(a[2]).all() and a[0] == pytest.approx(b[0], rel=1e-6)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5)
+    for name, off, r, c in a[3]:
+        ga, gb = a[2][off:off + r * c], b[2][off:off + r * c]
+        assert np.linalg.norm(ga - gb) <= 1e-4 * np.linalg.norm(gb) + 1e-7 * np.linalg.norm(b[2]), name

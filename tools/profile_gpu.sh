@@ -4,7 +4,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/profile_gpu.sh r02'
 set -e
 TAG=${1:-run}
-WLS=${2:-"bilstm3x500 literal"}
+WLS=${2:-"bilstm3x500 literal deepspeech"}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -25,6 +25,10 @@ cd "$ROOT"
 if [ -x tools/sb_st ]; then
   timeout -k 5 60 tools/sb_st 500 16 500 2 0 > "$OUT/${TAG}_persist_stamps.log" 2>&1
   python3 tools/stamps_to_json.py bilstm3x500 "$OUT/${TAG}_persist_stamps.log" "$OUT/persist_stamps.json" > /dev/null
+fi
+if [ -x tools/sb_wide_st ]; then   # wide persistent kernels (Hp 2048): hipcc ... -DNASR_WSTAMP=1 tools/widebench.hip lstm.hip lstm_wide.hip
+  WIDE_STAMPS=1 timeout -k 5 120 tools/sb_wide_st 500 32 0 > "$OUT/${TAG}_wide_stamps.log" 2>&1
+  python3 tools/stamps_to_json.py --wide deepspeech "$OUT/${TAG}_wide_stamps.log" "$OUT/persist_stamps.json" > /dev/null
 fi
 head -8 "$OUT/${TAG}_bilstm3x500_kernel_stats.csv"
 cat "$OUT/${TAG}_pmc_bilstm3x500.txt"
