@@ -130,10 +130,11 @@ def test_reference_shape_constructs_and_steps():
     feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=1, Lmin=2, Lmax=4)
     rs = np.random.RandomState(0)
     runs = {}
-    for mode in ('wide-persistent', 'per-step'):
+    wide_on = os.environ.get('NASR_PERSIST', '1')[:1] != '0' and os.environ.get('NASR_WIDE', '1')[:1] != '0'
+    for mode in (('wide-persistent', 'per-step') if wide_on else ('per-step',)):
         e = make_engine(spec, lr=1e-4)
-        assert e.recurrence_mode == 'wide-persistent'
-        if mode == 'per-step':
+        assert e.recurrence_mode == ('wide-persistent' if wide_on else 'per-step')
+        if mode == 'per-step' and wide_on:
             e.set_recurrence_mode(False)
         assert e.recurrence_mode == mode
         if 'p0' not in runs:
@@ -143,6 +144,8 @@ def test_reference_shape_constructs_and_steps():
         assert np.isfinite(losses).all() and losses[2] < losses[0]
         runs[mode] = (losses, e.get_params())
         e.close()
+    if not wide_on:
+        return
     np.testing.assert_allclose(runs['wide-persistent'][0], runs['per-step'][0], rtol=2e-5)
     d = runs['wide-persistent'][1] - runs['per-step'][1]
     # Adam's first steps move every weight by ~lr whatever its gradient: compare against that step size
