@@ -25,6 +25,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef WIDE_PF
+#define WIDE_PF 2        // k-tiles of A fragments read ahead of the MFMAs (tools/widebench A/B: 1, 2, 3)
+#endif
 #ifndef NASR_WSTAMP
 #define NASR_WSTAMP 0   // 1: s_memtime deltas per phase -> WideCtl::stamps (tools/widebench)
 #endif
@@ -260,15 +263,21 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
         // both 16 x 16 tiles of this M tile together; the A fragments of k-tile kt+1 are read while kt multiplies (the
         // scheduling barriers keep the compiler from hoisting every read to the top, which costs 64 registers per M tile)
         f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        h8 c0 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 0) * 64 + lane]);
-        h8 c1 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 1) * 64 + lane]);
+        // fragments of k-tiles kt+1 and kt+2 are in flight while kt multiplies (PF = prefetch distance)
+        constexpr int PF = WIDE_PF;
+        h8 q0[PF + 1], q1[PF + 1];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+          q0[j] = __builtin_bit_cast(h8, Alds[((j * MT + m) * 2 + 0) * 64 + lane]);
+          q1[j] = __builtin_bit_cast(h8, Alds[((j * MT + m) * 2 + 1) * 64 + lane]);
+        }
         wstatic_for<0, 8>([&](auto ktc) {
           constexpr int kt = decltype(ktc)::value;
-          h8 n0 = c0, n1 = c1;
-          if constexpr (kt < 7) {
-            n0 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 0) * 64 + lane]);
-            n1 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 1) * 64 + lane]);
+          if constexpr (kt + PF < 8) {
+            q0[(kt + PF) % (PF + 1)] = __builtin_bit_cast(h8, Alds[(((kt + PF) * MT + m) * 2 + 0) * 64 + lane]);
+            q1[(kt + PF) % (PF + 1)] = __builtin_bit_cast(h8, Alds[(((kt + PF) * MT + m) * 2 + 1) * 64 + lane]);
           }
+          const h8 c0 = q0[kt % (PF + 1)], c1 = q1[kt % (PF + 1)];
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][0][0], t0, 0, 0, 0);
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][1][0], t1, 0, 0, 0);
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][0][1], t0, 0, 0, 0);
@@ -276,8 +285,6 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][0][0], t0, 0, 0, 0);
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][1][0], t1, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          c0 = n0;
-          c1 = n1;
         });
         t0 *= osc[0];
         t1 *= osc[1];
@@ -632,15 +639,21 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
         // both 16 x 16 tiles of this M tile together; the A fragments of k-tile kt+1 are read while kt multiplies (the
         // scheduling barriers keep the compiler from hoisting every read to the top, which costs 64 registers per M tile)
         f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        h8 c0 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 0) * 64 + lane]);
-        h8 c1 = __builtin_bit_cast(h8, Alds[((0 * MT + m) * 2 + 1) * 64 + lane]);
+        // fragments of k-tiles kt+1 and kt+2 are in flight while kt multiplies (PF = prefetch distance)
+        constexpr int PF = WIDE_PF;
+        h8 q0[PF + 1], q1[PF + 1];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+          q0[j] = __builtin_bit_cast(h8, Alds[((j * MT + m) * 2 + 0) * 64 + lane]);
+          q1[j] = __builtin_bit_cast(h8, Alds[((j * MT + m) * 2 + 1) * 64 + lane]);
+        }
         wstatic_for<0, 8>([&](auto ktc) {
           constexpr int kt = decltype(ktc)::value;
-          h8 n0 = c0, n1 = c1;
-          if constexpr (kt < 7) {
-            n0 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 0) * 64 + lane]);
-            n1 = __builtin_bit_cast(h8, Alds[(((kt + 1) * MT + m) * 2 + 1) * 64 + lane]);
+          if constexpr (kt + PF < 8) {
+            q0[(kt + PF) % (PF + 1)] = __builtin_bit_cast(h8, Alds[(((kt + PF) * MT + m) * 2 + 0) * 64 + lane]);
+            q1[(kt + PF) % (PF + 1)] = __builtin_bit_cast(h8, Alds[(((kt + PF) * MT + m) * 2 + 1) * 64 + lane]);
           }
+          const h8 c0 = q0[kt % (PF + 1)], c1 = q1[kt % (PF + 1)];
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ub[kt][0][0], t0, 0, 0, 0);
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ub[kt][1][0], t1, 0, 0, 0);
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ub[kt][0][1], t0, 0, 0, 0);
@@ -648,8 +661,6 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_bwd_kernel(
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ub[kt][0][0], t0, 0, 0, 0);
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ub[kt][1][0], t1, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          c0 = n0;
-          c1 = n1;
         });
         const f32x4 si = *reinterpret_cast<const f32x4*>(sinv + 16 * m + 4 * (lane >> 4));
         t0 *= si * oun[0];
