@@ -615,12 +615,13 @@ int repack(nasr_ctx* h) {
     launch_repack_persist(h->P, h->off_u.data(), (int)h->off_u.size(), h->Upf, h->Upb, h->Hp,
                           h->rec_f16 ? h->Ucs : nullptr, h->st);
   } else {
-    for (int l = 0; l < h->L; ++l)
-      for (int d = 0; d < h->D; ++d) {
-        const size_t k = (size_t)l * h->D + d;
-        const size_t o = k * (size_t)h->Hp * h->N4;
-        launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
-      }
+    if (!h->wide)   // (a fall-back from the wide kernels calls repack again: persist_check)
+      for (int l = 0; l < h->L; ++l)
+        for (int d = 0; d < h->D; ++d) {
+          const size_t k = (size_t)l * h->D + d;
+          const size_t o = k * (size_t)h->Hp * h->N4;
+          launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
+        }
     if (h->wide) {   // column scales of every recurrent matrix, then the fp16-plane images of the wide forward kernel
       std::vector<TphScaleJob> jobs;
       for (size_t k = 0; k < h->off_u.size(); ++k)
