@@ -6,7 +6,8 @@ Writes a synthetic .scp / .pkl set (26 MFCC x 21 context = 546 features, 500 fra
 directory, trains the 3x500 bidirectional net for a few epochs at batch 16 on one GPU and prints the wall time per step of
 the last epochs - with the loader thread staging every next batch (the default) and with synchronous uploads.
 
-    python tools/e2e_train.py [utterances=64] [epochs=4]"""
+    python tools/e2e_train.py [utterances=64] [epochs=4] [network=networks.bilstm_ctc_net.BiLstm3x500CTCNet] [batch=16]
+    python tools/e2e_train.py 128 4 networks.deepspeech.DeepSpeech 32      # BASELINE.json configs[3] per GPU"""
 import os
 import pickle
 import shutil
@@ -31,7 +32,7 @@ samplerate=16000
 numcep=26
 numcontext=10
 label_context=0
-batch_size=16
+batch_size=%(batch)d
 epochs=%(epochs)d
 learningrate=0.0001
 model_dir=%(out)s/model
@@ -40,7 +41,7 @@ report_step=1000000
 num_gpus=1
 punc_regex=[^a-z0-9 ]
 sym_file=${MFCC Featurizer:output}/symbols
-network=networks.bilstm_ctc_net.BiLstm3x500CTCNet
+network=%(network)s
 
 [Train]
 input=${MFCC Featurizer:output}/train.scp
@@ -56,6 +57,8 @@ output=%(out)s
 def main():
     n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    network = sys.argv[3] if len(sys.argv) > 3 else 'networks.bilstm_ctc_net.BiLstm3x500CTCNet'
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 16
     out = tempfile.mkdtemp(prefix='nasr_e2e_')
     try:
         sym = Symbols(0)
@@ -77,8 +80,8 @@ def main():
             fh.write('\n'.join(names) + '\n')
         cfgp = os.path.join(out, 'e2e.config')
         with open(cfgp, 'w') as fh:
-            fh.write(CONFIG % dict(out=out, epochs=epochs))
-        steps_per_epoch = (n_utt + 15) // 16
+            fh.write(CONFIG % dict(out=out, epochs=epochs, network=network, batch=batch))
+        steps_per_epoch = (n_utt + batch - 1) // batch
         for label, prefetch in (('overlapped loop: next batch loaded + staged under the running step', 2),
                                 ('reference order: load, upload, train', 0),
                                 ('overlapped loop, again', 2)):
@@ -105,8 +108,8 @@ def main():
             dt = (stamps[-1] - stamps[warm]) / (len(stamps) - 1 - warm)
             gaps = np.diff(np.asarray(stamps)) * 1e3
             med = float(np.median(gaps[warm:]))
-            print('%-72s mean %.3f ms, median %.3f ms per step  (%d steps of 8000 frames: %.3f M frames/s at the median)'
-                  % (label, dt * 1e3, med, len(stamps) - 1 - warm, 8000 / med / 1e3), flush=True)
+            print('%-72s mean %.3f ms, median %.3f ms per step  (%d steps of %d frames: %.3f M frames/s at the median)'
+                  % (label, dt * 1e3, med, len(stamps) - 1 - warm, 500 * batch, 500 * batch / med / 1e3), flush=True)
             print('   step-to-step gaps (ms): ' + ' '.join('%.1f' % g for g in gaps), flush=True)
         if os.environ.get('NASR_E2E_TIMERS'):
             # wall time of the engine calls train() and the loader thread make (monkeypatched timers), staged loop
