@@ -3,12 +3,12 @@ BASELINE.json configs[3]) through the C ABI against the fp
 hash of (seed, pass counter, stage, frame, utterance, unit) that the oracle computes identically (TensorFlow's random
 stream cannot be reproduced: parity of the masks themselves is by definition, parity of everything else by comparison).
 Tolerances as in tests/test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import nasr_oracle as O
-
-import os
 
 pytestmark = pytest.mark.gpu
 
@@ -225,6 +225,61 @@ def test_reference_widths_match_the_oracle():
     assert loss == pytest.approx(loss_o, rel=5e-5)
     g_o = O.flatten(grads_o)
     assert np.linalg.norm(grads - g_o) <= 1e-2 * np.linalg.norm(g_o)
+    e.close()
+
+
+_LONG = {}
+
+
+def _long_case():
+    """configs[3] per GPU over > 100 dependent timesteps: B 32, ragged T <= 128, dropout 0.05, checked by oracle/cref (the C
+    restatement, pinned against the fp64 oracle in tests/test_cref.py; the fp64 oracle would need ~10 minutes here).
+    Computed once for both recurrence modes."""
+    if not _LONG:
+        from oracle import cref
+        cref.set_threads(cref.usable_cpus())
+        spec = _reference_spec()
+        B, T = 32, 128
+        batch = O.synth_batch(spec, B, T, seed=7, var_len=True, Lmin=10, Lmax=30)
+        seed, counter = 4567, 3
+        params = _params_away_from_kinks(spec, 2)
+        assert O.deepspeech_kink_margin(spec, params, batch[0], batch[1], drop=(seed, counter)) > 1e-2
+        flat = O.flatten(params).astype(np.float32)
+        lo, nllo, go, lgo = cref.loss_and_grads(spec, flat, *batch, want_logits=True, drop=(seed, counter))
+        _LONG.update(spec=spec, batch=batch, drop=(seed, counter), flat=flat, ref=(lo, nllo, go, lgo))
+    return _LONG
+
+
+@pytest.mark.parametrize("mode", ['wide-persistent', 'per-step'])
+def test_reference_widths_over_128_timesteps_match_the_c_restatement(mode):
+    """networks/deepspeech.py:70-121 at its own widths over 64..128 dependent timesteps per utterance: logits, loss and
+    every gradient tensor against oracle/cref, once through the wide persistent kernels (fp16-plane BPTT with its
+    per-utterance dG scale, lstm_wide.hip) and once through the per-step kernels at Hp = 2048 (lstm.hip) - each pinned to a
+    CPU restatement instead of to the other."""
+    if mode == 'wide-persistent' and (os.environ.get('NASR_PERSIST', '1')[:1] == '0' or os.environ.get('NASR_WIDE', '1')[:1] == '0'):
+        pytest.skip('NASR_PERSIST=0 / NASR_WIDE=0 force the per-step kernels')
+    c = _long_case()
+    spec, (feats, seq_len, labels, label_len), (seed, counter) = c['spec'], c['batch'], c['drop']
+    lo, nllo, go, lgo = c['ref']
+    e = make_engine(spec)
+    if mode == 'per-step':
+        e.set_recurrence_mode(False)
+    assert e.recurrence_mode == mode
+    e.set_params(c['flat'])
+    e.set_dropout_state(seed, counter)
+    logits = e.forward(feats, seq_len)
+    np.testing.assert_allclose(logits, lgo, atol=1e-4 * max(1.0, np.abs(lgo).max()))
+    e.set_dropout_state(seed, counter)
+    loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+    assert e.recurrence_mode == mode                       # no abort, no fall-back on the way
+    assert loss == pytest.approx(lo, rel=2e-5)
+    np.testing.assert_allclose(nll, nllo, rtol=2e-5)
+    scale = np.linalg.norm(go)
+    for name, off, r, cc in e.tensors():
+        g, g_o = grads[off:off + r * cc], go[off:off + r * cc]
+        err = np.linalg.norm(g - g_o) / (np.linalg.norm(g_o) + 1e-2 * scale / np.sqrt(len(e.tensors())))
+        assert err <= 1e-4, (name, err)
+    assert np.linalg.norm(grads - go) <= 1e-4 * scale
     e.close()
 
 

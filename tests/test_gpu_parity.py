@@ -57,6 +57,9 @@ CASES = [
     (O.ModelSpec(1, 8, 1, True, 'concat', 3), 1, 5, False),         # one feature, two label classes + blank
     (O.ModelSpec(1100, 33, 1, False, 'none', 70), 9, 11, True),     # features wider than a GEMM K panel, C > 64
     (O.ModelSpec(14, 48, 4, True, 'concat', 150), 5, 14, True),     # four layers, C > 128
+    # BASELINE.json configs[0] at its stated shape: lstm_ctc_net 1x128, 8 kHz / 13 MFCC (config/8000sr_13mfcc.config), batch 4
+    (O.ModelSpec(13, 128, 1, False, 'none', 29), 4, 300, True),
+    (O.ModelSpec(13, 128, 1, False, 'none', 29), 4, 300, False),
 ]
 
 
