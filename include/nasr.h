@@ -88,7 +88,10 @@ typedef struct {
  * with torch.distributed collectives.  Parameters start at zero: call nasr_set_params. */
 int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_handle* out);
 int nasr_destroy(nasr_handle h);
-const char* nasr_last_error(nasr_handle h); /* h may be NULL: error of a failed nasr_create */
+/* message of the CALLING THREAD's last failed call on h (h NULL: of a failed nasr_create); valid until that thread's next
+ * failing call.  Per thread, so that nasr_stage_batch* on a loader thread and the training thread never read or overwrite
+ * each other's text. */
+const char* nasr_last_error(nasr_handle h);
 const char* nasr_backend(nasr_handle h);    /* "hip-gfx950" */
 int nasr_synchronize(nasr_handle h);        /* hipStreamSynchronize on the handle's stream */
 
@@ -217,9 +220,16 @@ int nasr_step_void(nasr_handle h, int* void_out);
  * this rank's forward recurrence aborted, the values are meaningless (then use nasr_step_void and repeat the step).
  * nasr_settle_step(h, previous, &v) waits for the END of the latest (previous = 0) or the one-before-latest (1) step
  * that reached nasr_apply_adam and says whether it was void (on every rank: the fault word is all-reduced with the
- * gradients); a void step's Adam launch was a no-op and is taken out of the step count. */
+ * gradients); a void step's Adam launch was a no-op and is taken out of the step count.
+ * A host that runs more than one step ahead names the step instead: nasr_step_token(h) = the sequence number of the
+ * optimiser step nasr_apply_adam enqueued last (> 0; 0 = none yet), nasr_settle_token(h, token, &v) waits for the end of
+ * exactly that step.  The library remembers the last 4 steps; an older token is NASR_ERR_STATE.  (What the reference
+ * gets from sess.run returning, tfnetwork.py:188-190: the step is over and its update applied - here per step, without a
+ * stream synchronisation.) */
 int nasr_get_step_results(nasr_handle h, float* loss_out, int* fault_out, int32_t* ids_out, int32_t* lens_out);
 int nasr_settle_step(nasr_handle h, int previous, int* void_out);
+int64_t nasr_step_token(nasr_handle h);
+int nasr_settle_token(nasr_handle h, int64_t token, int* void_out);
 int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the resident batch */
 
 /* TensorFlowNetwork.train fetches mean_ler with every step (networks/tfnetwork.py:188-189): with

@@ -30,6 +30,7 @@ SYMBOLS = [
     'nasr_step_void', 'nasr_get_persist_stats', 'nasr_stage_batch', 'nasr_stage_batch_context', 'nasr_commit_batch',
     'nasr_discard_batch', 'nasr_set_bucket_defer', 'nasr_comm_unique_id', 'nasr_comm_init', 'nasr_comm_size',
     'nasr_comm_allreduce_grads', 'nasr_comm_mean', 'nasr_comm_destroy', 'nasr_get_step_results', 'nasr_settle_step',
+    'nasr_step_token', 'nasr_settle_token',
 ]
 
 
@@ -133,6 +134,8 @@ def load():
         'nasr_comm_destroy': (c_int, [H]),
         'nasr_get_step_results': (c_int, [H, fp, POINTER(c_int), ip, ip]),
         'nasr_settle_step': (c_int, [H, c_int, POINTER(c_int)]),
+        'nasr_step_token': (c_int64, [H]),
+        'nasr_settle_token': (c_int, [H, c_int64, POINTER(c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

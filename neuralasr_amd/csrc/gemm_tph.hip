@@ -19,6 +19,8 @@
 // barrier as before), two 64 KiB LDS buffers, 8 LDS-DMA instructions per wave and step.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace nasr {
 
 namespace {
@@ -52,6 +54,11 @@ struct GemmTPHParams {
   int nbatch;
   long long a_bstride, b_bstride, c_bstride, ainv_bstride, binv_bstride;
   int a_kb_shift1;
+  // XCD-aware tile order (swz != 0, 1-D grid): workgroup L runs on XCD L % 8 (observed dispatch order; speed only, any
+  // placement gives the same result), so the 8 XCDs form a pr x pc x pz process grid over (row tiles, column tiles,
+  // K slices x batch) and the i-th workgroup of an XCD takes tile (r fastest, then c, then z) of its own sub-grid:
+  // the workgroups that run together on one XCD share their operand tiles through that XCD's L2.
+  int swz, gx, gy, gz, pr, pc, pz, sr, sc, sz;    // sr x sc x sz: sub-grid of one XCD
 };
 
 __device__ __forceinline__ void emit_h2(const float (&x)[8], float s, unsigned char* dst) {
@@ -340,8 +347,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
   constexpr int BUFB = NT * HTB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 256;
-  const int bz = p.nbatch > 1 ? (int)(blockIdx.z % p.nbatch) : 0, zs = p.nbatch > 1 ? (int)(blockIdx.z / p.nbatch) : (int)blockIdx.z;
+  int bx = blockIdx.x, by = blockIdx.y, bzz = blockIdx.z;
+  if (p.swz) {
+    const int L = blockIdx.x, x = L & 7, i = L >> 3;
+    const int xr = x % p.pr, xc = (x / p.pr) % p.pc, xz = x / (p.pr * p.pc);
+    const int r = i % p.sr, c = (i / p.sr) % p.sc, z = i / (p.sr * p.sc);
+    by = xr * p.sr + r; bx = xc * p.sc + c; bzz = xz * p.sz + z;
+    if (by >= p.gy || bx >= p.gx || bzz >= p.gz) return;      // padding of an uneven sub-grid (block-uniform)
+  }
+  const int m0 = by * TM, n0 = bx * 256;
+  const int bz = p.nbatch > 1 ? (int)(bzz % p.nbatch) : 0, zs = p.nbatch > 1 ? (int)(bzz / p.nbatch) : bzz;
   const int kb0 = zs * p.kb_chunk;                       // even
   const int kb1 = min(p.kbs, kb0 + p.kb_chunk);
   const int wm = w >> 2, wn = w & 3;
@@ -432,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
         const int row = m0 + wm * (32 * TMW) + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= p.M) continue;
         const float v = acc[mi][ni][r] * (ainv[row] * sb);        // powers of two: exact
-        if (p.split_k > 1) p.slabs[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+        if (p.split_k > 1) p.slabs[((size_t)bzz * p.M + row) * p.N + col] = v;
         else p.C[(size_t)bz * p.c_bstride + (size_t)row * p.ldc + col] = v + bv;
       }
     }
@@ -484,6 +499,26 @@ void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st) {
   p.ainv_bstride = (long long)g.ainv_bstride; p.binv_bstride = (long long)g.binv_bstride;
   p.a_kb_shift1 = g.a_kshift1 / 16;
   dim3 grid((g.N + 255) / 256, (g.M + tm - 1) / tm, p.split_k * p.nbatch);
+  p.swz = 0;
+  p.gx = (int)grid.x; p.gy = (int)grid.y; p.gz = (int)grid.z;
+  p.pr = p.pc = p.pz = 1; p.sr = p.gy; p.sc = p.gx; p.sz = p.gz;
+  {
+    static const int mode = [] { const char* e = getenv("NASR_GEMM_SWZ"); return e ? atoi(e) : 1; }();
+    // process grid with the least fabric traffic pc * |A| + pr * |B| (an XCD fetches the A tiles of its rows once for all
+    // of its columns and vice versa; K slices replicate nothing) among those that pad the grid by at most 1/8
+    double best = 1e300;
+    const long long total = (long long)p.gx * p.gy * p.gz;
+    for (int pz = 1; pz <= 8 && mode; pz *= 2)
+      for (int pr = 1; pr * pz <= 8; pr *= 2) {
+        const int pc = 8 / (pz * pr);
+        const int sr = (p.gy + pr - 1) / pr, sc = (p.gx + pc - 1) / pc, sz = (p.gz + pz - 1) / pz;
+        const long long padded = 8LL * sr * sc * sz;
+        if (padded * 8 > total * 9) continue;
+        const double cost = (double)pc * g.M + (double)pr * g.N + 1e-3 * (padded - total);
+        if (cost < best) { best = cost; p.swz = 1; p.pr = pr; p.pc = pc; p.pz = pz; p.sr = sr; p.sc = sc; p.sz = sz; }
+      }
+    if (p.swz) grid = dim3(8 * p.sr * p.sc * p.sz, 1, 1);
+  }
   if (tm == 192) hipLaunchKernelGGL(gemm_tph_kernel<3>, grid, dim3(512), TPH_LDS, st, p);
   else hipLaunchKernelGGL(gemm_tph_kernel<4>, grid, dim3(512), TPH_LDS, st, p);
   if (p.split_k > 1) launch_reduce_slabs(g.slabs, p.split_k, (int64_t)p.nbatch * g.M * g.N, g.C, st);

@@ -11,6 +11,11 @@
 
 namespace nasr {
 
+// Fault-injection hooks of the tests (NASR_PERSIST_FAULT, NASR_WIDE_FAULT, ...): honoured only in a process that had
+// NASR_TEST_HOOKS=1 in its environment when the library first asked - a stray variable in a production run does nothing,
+// and a production launch costs one cached bool instead of getenv calls.
+const char* test_hook(const char* name);
+
 // ---- GEMM (gemm.hip): C[M,N] = opA[M,K] * opB[K,N] (+bias[n]) on v_mfma_f32_32x32x2_f32 ----
 struct GemmDesc {
   const float* A;

@@ -716,9 +716,9 @@ static PersistGeom make_geom(const LstmDims& dm, bool bwd) {
   g.ub = (dm.Bp + NGD - 1) / NGD;
   if (g.ub > 4) g.ub = 4;
   g.rounds = (dm.Bp + NGD * g.ub - 1) / (NGD * g.ub);
-  const char* e = getenv("NASR_PERSIST_FAULT");
+  const char* e = test_hook("NASR_PERSIST_FAULT");
   g.inject = (e && *e) ? atoi(e) : -1;
-  const char* ek = getenv("NASR_PERSIST_FAULT_KERNEL");     // "fwd" / "bwd": inject into that kernel only
+  const char* ek = test_hook("NASR_PERSIST_FAULT_KERNEL");     // "fwd" / "bwd": inject into that kernel only
   if (ek && *ek && ((ek[0] == 'b') != bwd)) g.inject = -1;
   g.fault = nullptr;
   return g;

@@ -814,8 +814,8 @@ void launch_lstm_wide_bwd(const LstmDims& dm, int d, const void* Uwb, const floa
   (void)hipMemsetAsync(inbox, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
   (void)hipMemsetAsync(px, 0xff, wide_px_bytes(dm.Bp), st);
   WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, 0, fault};
-  if (const char* e = getenv("NASR_WIDE_FAULT_BWD")) gm.inject = atoi(e);
-  if (const char* e = getenv("NASR_WIDE_SCALE_SHIFT")) gm.scale_shift = atoi(e);   // test hook: > 10 drives dG * S out of the fp16 range
+  if (const char* e = test_hook("NASR_WIDE_FAULT_BWD")) gm.inject = atoi(e);
+  if (const char* e = test_hook("NASR_WIDE_SCALE_SHIFT")) gm.scale_shift = atoi(e);   // test hook: > 10 drives dG * S out of the fp16 range
   const int MT = dm.Bp / 16;
 #define NASR_WIDE(MTV)                                                                                               \
   hipLaunchKernelGGL((lstm_wide_bwd_kernel<MTV>), dim3(256), dim3(512), WideLdsB<MTV>::END * 16, st,                 \
@@ -837,7 +837,7 @@ void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float
   (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
   (void)hipMemsetAsync(part, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
   WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, 0, fault};
-  if (const char* e = getenv("NASR_WIDE_FAULT")) gm.inject = atoi(e);
+  if (const char* e = test_hook("NASR_WIDE_FAULT")) gm.inject = atoi(e);
   const int MT = dm.Bp / 16;
 #define NASR_WIDE(MTV)                                                                                               \
   hipLaunchKernelGGL((lstm_wide_fwd_kernel<MTV>), dim3(256), dim3(512), WideLds<MTV>::END * 16, st,                  \

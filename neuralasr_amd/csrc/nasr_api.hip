@@ -27,6 +27,10 @@ using namespace nasr;
 namespace {
 
 std::string g_create_error;
+// nasr_last_error: the message of the calling thread's last failed call (nasr_stage_batch* may fail on a loader thread
+// while the training thread is inside another call of the same handle: neither sees nor overwrites the other's text)
+thread_local std::string t_err;
+thread_local const void* t_err_handle = nullptr;
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -143,7 +147,6 @@ struct nasr_ctx {
   void* wpx = nullptr;                 // BPTT: partial dh through the XCD's L2
   WideCtl* wctl = nullptr;
   unsigned* perr = nullptr;            // host-mapped sticky error word
-  std::string err;
   // in-library gradient exchange (nasr_comm_*): one RCCL rank per handle, collectives on a side stream
   void* comm = nullptr;                  // ncclComm_t
   int comm_rank = 0, comm_n = 1;
@@ -213,9 +216,11 @@ struct nasr_ctx {
   struct StepRes { void* host = nullptr; size_t cap = 0; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int B = 0, Bp = 0, Tp = 0; };
   StepRes res[2];
   int res_cur = 0;
-  struct StepEnd { float* host = nullptr; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; };
-  StepEnd endw[2];
+  struct StepEnd { float* host = nullptr; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int64_t token = 0; };
+  static constexpr int NEND = 4;             // steps whose end the host may still ask about (nasr_settle_token)
+  StepEnd endw[NEND];
   int end_cur = 0;
+  int64_t step_token = 0;                    // sequence number of the optimiser step enqueued last
   uint32_t stamp_seq = 0;
 
   // resident batch
@@ -255,7 +260,8 @@ struct nasr_ctx {
   nasr_phase_times last_times;
 
   int fail(int code, const std::string& m) {
-    err = m;
+    t_err = m;
+    t_err_handle = this;
     return code;
   }
 };
@@ -1501,7 +1507,7 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       return bail(NASR_ERR_HIP, "hipStreamCreate failed");
     h->own_stream = true;
   }
-  if (build_layout(h) != NASR_OK) return bail(NASR_ERR_ARG, h->err);
+  if (build_layout(h) != NASR_OK) return bail(NASR_ERR_ARG, t_err);
   {
     h->sc_wr.resize(h->L); h->sc_wc.resize(h->L);
     h->sc_dr.resize(h->ndense); h->sc_dc.resize(h->ndense); h->sc_yr.resize(h->ndense); h->sc_yc.resize(h->ndense);
@@ -1747,7 +1753,10 @@ int nasr_destroy(nasr_handle h) {
   return NASR_OK;
 }
 
-const char* nasr_last_error(nasr_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* nasr_last_error(nasr_handle h) {
+  if (!h) return g_create_error.c_str();
+  return t_err_handle == h ? t_err.c_str() : "";
+}
 const char* nasr_backend(nasr_handle) { return "hip-gfx950"; }
 
 int nasr_synchronize(nasr_handle h) {
@@ -1927,9 +1936,10 @@ int nasr_apply_adam(nasr_handle h, float grad_scale) {
     int rc = repack(h);
     if (rc) return rc;
     // the step's fault word as it stands now (all-reduced with the gradients): read later, without a stream sync
-    h->end_cur ^= 1;
+    h->end_cur = (h->end_cur + 1) % nasr_ctx::NEND;
     nasr_ctx::StepEnd& e = h->endw[h->end_cur];
     e.seq = ++h->stamp_seq;
+    e.token = ++h->step_token;
     hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, h->st, e.stamp, e.seq, e.host, (const float*)h->Gbase);
     e.valid = true;
   }
@@ -2034,11 +2044,9 @@ int nasr_get_step_results(nasr_handle h, float* loss_out, int* fault_out, int32_
   return NASR_OK;
 }
 
-int nasr_settle_step(nasr_handle h, int previous, int* void_out) {
-  if (!h || !void_out) return NASR_ERR_ARG;
-  *void_out = 0;
-  nasr_ctx::StepEnd& e = h->endw[previous ? h->end_cur ^ 1 : h->end_cur];
-  if (!e.valid) return NASR_OK;
+}  // extern "C"
+namespace {
+int settle_end(nasr_ctx* h, nasr_ctx::StepEnd& e, int* void_out) {
   // the end of THAT step only
   if (!wait_stamp(e.stamp, e.seq, 60.0)) return h->fail(NASR_ERR_HIP, "nasr_settle_step: the step did not end within 60 s");
   if (*e.host != 0.f) {
@@ -2046,6 +2054,28 @@ int nasr_settle_step(nasr_handle h, int previous, int* void_out) {
     (void)persist_check(h);   // a local abort: this handle continues on the per-step kernels (message in last_error)
   }
   return NASR_OK;
+}
+}  // namespace
+extern "C" {
+
+int nasr_settle_step(nasr_handle h, int previous, int* void_out) {
+  if (!h || !void_out) return NASR_ERR_ARG;
+  *void_out = 0;
+  nasr_ctx::StepEnd& e = h->endw[previous ? (h->end_cur + nasr_ctx::NEND - 1) % nasr_ctx::NEND : h->end_cur];
+  if (!e.valid) return NASR_OK;
+  return settle_end(h, e, void_out);
+}
+
+int64_t nasr_step_token(nasr_handle h) { return h ? h->step_token : -1; }
+
+int nasr_settle_token(nasr_handle h, int64_t token, int* void_out) {
+  if (!h || !void_out) return NASR_ERR_ARG;
+  *void_out = 0;
+  if (token <= 0 || token > h->step_token) return h->fail(NASR_ERR_ARG, "nasr_settle_token: no such step");
+  for (auto& e : h->endw)
+    if (e.valid && e.token == token) return settle_end(h, e, void_out);
+  return h->fail(NASR_ERR_STATE, "nasr_settle_token: the library remembers the last " + std::to_string(nasr_ctx::NEND) +
+                                     " optimiser steps; this token is older");
 }
 
 int nasr_resident_frames(nasr_handle h, int64_t* frames) {

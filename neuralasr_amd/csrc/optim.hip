@@ -8,7 +8,17 @@
 // One pass reads g,m,v,p and writes m,v,p with 16-byte accesses: 28 B/param, HBM-bound.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace nasr {
+
+const char* test_hook(const char* name) {
+  static const bool enabled = [] {
+    const char* e = getenv("NASR_TEST_HOOKS");
+    return e && e[0] == '1';
+  }();
+  return enabled ? getenv(name) : nullptr;
+}
 
 // t <- t + 1 and lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in double, by one thread, unless the step is void
 __global__ void adam_prepare_kernel(AdamDev* st, const float* __restrict__ fault, float lr, float b1, float b2) {

@@ -32,6 +32,35 @@ class _SampleUnpickler(pickle.Unpickler):
         raise pickle.UnpicklingError('refusing to load %s.%s from a sample file' % (module, name))
 
 
+class _SwitchInterval:
+    """Process-wide, reference-counted override of sys.setswitchinterval: the first generator in lowers it, the last one
+    out restores what it found - nested or abandoned prefetch generators (train + validation) cannot leave each other's
+    saved value behind."""
+
+    def __init__(self, seconds):
+        import threading
+        self.seconds, self.users, self.saved, self.lock = seconds, 0, None, threading.Lock()
+
+    def __enter__(self):
+        import sys
+        with self.lock:
+            if self.users == 0:
+                self.saved = sys.getswitchinterval()
+                sys.setswitchinterval(min(self.saved, self.seconds))
+            self.users += 1
+
+    def __exit__(self, *exc):
+        import sys
+        with self.lock:
+            self.users -= 1
+            if self.users == 0:
+                sys.setswitchinterval(self.saved)
+        return False
+
+
+_short_switch_interval = _SwitchInterval(2e-4)
+
+
 class DataSet:
     def __init__(self, filename, config):
         self.filename = filename
@@ -127,23 +156,20 @@ class DataSet:
 
         # The loader thread holds the interpreter lock through unpickling and array assembly; with CPython's default
         # 5 ms switch interval the training thread can wait that long to get it back after the GPU step has finished.
-        import sys
-        old_interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(old_interval, 2e-4))
         t = threading.Thread(target=worker, name='nasr-prefetch', daemon=True)
-        t.start()
-        try:
-            while True:
-                item = q.get()
-                if item is done:
-                    break
-                if isinstance(item, BaseException):
-                    raise item
-                yield item
-        finally:
-            quit_.set()
-            t.join()
-            sys.setswitchinterval(old_interval)
+        with _short_switch_interval:
+            t.start()
+            try:
+                while True:
+                    item = q.get()
+                    if item is done:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    yield item
+            finally:
+                quit_.set()
+                t.join()
 
     def get_feature_shape(self):
         return [self.config.batch_size, None, self.config.feature_size]

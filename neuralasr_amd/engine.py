@@ -326,6 +326,17 @@ class Engine:
         self._ck(self.lib.nasr_settle_step(self.h, int(bool(previous)), byref(v)))
         return bool(v.value)
 
+    def step_token(self):
+        """Sequence number of the optimiser step apply_adam() enqueued last (include/nasr.h, nasr_step_token)."""
+        return int(self.lib.nasr_step_token(self.h))
+
+    def settle_token(self, token):
+        """True when optimiser step `token` was void on every rank; waits for the end of exactly that step."""
+        from ctypes import c_int
+        v = c_int()
+        self._ck(self.lib.nasr_settle_token(self.h, int(token), byref(v)))
+        return bool(v.value)
+
     def resident_frames(self):
         n = c_int64()
         self._ck(self.lib.nasr_resident_frames(self.h, byref(n)))

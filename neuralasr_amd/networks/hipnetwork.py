@@ -225,8 +225,8 @@ class HipNetwork(Network):
         n, mine = self._towers()
         if self.async_step and len(mine) == 1 and self.train_ler_decoder == 'greedy':
             f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, mine[0])
-            self._begun = ('async', (mfccs, f, l, s, ll, n))
-            self._enqueue_step(mfccs, f, l, s, ll, n)
+            batch = (mfccs, f, l, s, ll, n)
+            self._begun = ('async', (batch, self._enqueue_step(*batch)))
         else:
             self._begun = ('sync', (mfccs, labels, seq_len, labels_len))
 
@@ -236,7 +236,7 @@ class HipNetwork(Network):
         kind, batch = self._begun
         self._begun = None
         if kind == 'async':
-            return self._finish_async(batch)
+            return self._finish_async(*batch)
         return self._train_sync(*batch)
 
     def _train_sync(self, mfccs, labels, seq_len, labels_len):
@@ -253,7 +253,8 @@ class HipNetwork(Network):
 
     # ------------------------------------------------------------------ the fast path of train()
     def _enqueue_step(self, mfccs, f, l, s, ll, n):
-        """Everything of one optimisation step, enqueued without waiting for any of it."""
+        """Everything of one optimisation step, enqueued without waiting for any of it.  Returns the step's token
+        (nasr_step_token): the name under which its end can be asked about later, however many steps follow."""
         ticket = self._take_staged(mfccs)
         if ticket is not None:
             self.engine.commit_batch(ticket)
@@ -270,53 +271,56 @@ class HipNetwork(Network):
             else:
                 self.coll.all_reduce_sum_(self._grad_tensor)
         self.engine.apply_adam(1.0 / n)
+        return self.engine.step_token()
 
     def _redo_step(self, batch, why):
-        """A void step's batch again, start to finish (every rank takes this path at the same point of its call sequence:
-        the fault word is all-reduced with the gradients)."""
+        """A void step's batch again, start to finish, until it counts; returns the (loss, mean_ler) of the attempt that
+        did.  Every rank takes this path at the same point of its call sequence and runs the same number of attempts: the
+        fault word is all-reduced with the gradients, so 'void' is the same answer everywhere."""
         mfccs, f, l, s, ll, n = batch
         for attempt in range(3):
             self.logger.warning('%s: repeating its batch' % why)
-            self._enqueue_step(None, f, l, s, ll, n)
-            if not self.engine.settle_step(previous=False):
-                return
+            token = self._enqueue_step(None, f, l, s, ll, n)
+            loss, _, hyps = self.engine.step_results(len(s), f.shape[1])
+            if not self.engine.settle_token(token):
+                return loss, self.engine.label_error_rate(hyps, l, ll)
         raise RuntimeError('a training step stayed void after 3 attempts')
 
     def _settle(self):
         """Before anything that is not the next fast-path step (validation, checkpoint, decode, the slow path): wait for
         the last fast-path step and repeat it if it was void."""
         if self._pending is not None:
-            batch, self._pending = self._pending, None
-            if self.engine.settle_step(previous=False):
+            (batch, token), self._pending = self._pending, None
+            if self.engine.settle_token(token):
                 self._redo_step(batch, 'the last training step was void (persistent recurrence aborted on some rank)')
 
-    def _finish_async(self, batch):
+    def _finish_async(self, batch, token):
         mfccs, f, l, s, ll, n = batch
         loss, fwd_fault, hyps = self.engine.step_results(len(s), f.shape[1])
         if fwd_fault:
             # THIS rank's forward recurrence aborted: its loss and decode mean nothing.  The step is void on every rank
-            # (the fault word travels with the gradients); it is repeated below, where every rank notices it.
+            # (the fault word travels with the gradients); it is repeated where every rank notices it.
             loss, ler = float('nan'), float('nan')
         else:
             ler = self.engine.label_error_rate(hyps, l, ll)
         # the step BEFORE this one has ended by now (stream order): was it void?
-        prev, self._pending = self._pending, batch
-        if prev is not None and self.engine.settle_step(previous=True):
-            self._redo_step(prev, 'step %d was void (persistent recurrence aborted on some rank)' % (self.global_step - 1))
-        if fwd_fault and self.coll.world == 1:
+        prev, self._pending = self._pending, (batch, token)
+        if prev is not None and self.engine.settle_token(prev[1]):
+            # This step was enqueued before anybody knew: whatever voided the previous one (a co-tenant, a placement) may
+            # have voided it too.  Learn its fate BEFORE anything else is enqueued, then repeat what was void, in order.
+            self._pending = None
+            cur_void = self.engine.settle_token(token)
+            self._redo_step(prev[0], 'step %d was void (persistent recurrence aborted on some rank)' % (self.global_step - 1))
+            if cur_void:
+                loss, ler = self._redo_step(batch, 'step %d was void as well' % self.global_step)
+        elif fwd_fault and self.coll.world == 1:
             # single process: nobody else to keep in step with - settle this one now and report the repeat's values
             self._pending = None
-            self.engine.settle_step(previous=False)
-            self.logger.warning('step %d was void (persistent recurrence aborted): repeating it' % self.global_step)
-            for attempt in range(3):
-                self._enqueue_step(None, f, l, s, ll, n)
-                loss, again, hyps = self.engine.step_results(len(s), f.shape[1])
-                if not self.engine.settle_step(previous=False) and not again:
-                    ler = self.engine.label_error_rate(hyps, l, ll)
-                    break
-            else:
-                raise RuntimeError('training step %d stayed void after 3 attempts' % self.global_step)
+            self.engine.settle_token(token)
+            loss, ler = self._redo_step(batch, 'step %d was void (persistent recurrence aborted)' % self.global_step)
         if self.coll.world > 1:
+            # (a rank-local forward fault leaves NaN here on every rank: train_model keeps such a step out of its means;
+            # the step itself is repeated one call later, where every rank sees the fault word)
             loss, ler = self.coll.mean_scalars([loss, ler])
         return np.float32(loss), np.float32(ler)
 

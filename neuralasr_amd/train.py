@@ -23,17 +23,25 @@ def train_model(dataTrain, datavalid, config, prefetch=2):
     logger.info('Label Dimensions: ' + str(dataTrain.get_label_shape()))
     network = config.load_network(fortraining=True)
     spent, loss_sum, ler_sum = 0.0, 0.0, 0.0     # train_time_sec is never reset (train.py:20,26,34)
+    counted = 0                                  # steps of the window whose values count (all of them, normally)
     split = prefetch and all(hasattr(network, a) for a in ('begin_step', 'finish_step', 'stage_batch'))
 
     def report(loss, mean_ler):
-        nonlocal loss_sum, ler_sum
-        loss_sum += loss
-        ler_sum += mean_ler
+        nonlocal loss_sum, ler_sum, counted
+        # a step whose forward pass was void on some rank (HipNetwork: a persistent-recurrence abort, repeated one call
+        # later) reports NaN on every rank: it stays out of the window's means instead of turning them into NaN
+        if loss == loss and mean_ler == mean_ler:
+            loss_sum += loss
+            ler_sum += mean_ler
+            counted += 1
         if network.global_step % config.report_step == 0:
             network.save_checkpoint()
-            logger.info('Step: %04d' % network.global_step + ', cost = %.4f' % (loss_sum / config.report_step) +
-                        ', ler = %.4f' % (ler_sum / config.report_step) + ', time = %.4f' % spent)
+            # train.py:32-34 divides by report_step; `counted` equals it unless a void step was left out
+            den = counted if 0 < counted < config.report_step else config.report_step
+            logger.info('Step: %04d' % network.global_step + ', cost = %.4f' % (loss_sum / den) +
+                        ', ler = %.4f' % (ler_sum / den) + ', time = %.4f' % spent)
             loss_sum = ler_sum = 0.0
+            counted = 0
             if datavalid:
                 if not datavalid.has_more_batches():
                     datavalid.reset_epoch()

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the fault-injection hooks of libnasr (NASR_PERSIST_FAULT, NASR_WIDE_FAULT, ...) only exist for a process that says so
+os.environ.setdefault('NASR_TEST_HOOKS', '1')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -452,3 +452,57 @@ def test_async_train_repeats_a_step_whose_backward_pass_was_void(tmp_path, monke
     assert net.engine.recurrence_mode == 'per-step' and net.global_step == 2
     assert net.engine.get_adam_state()[2] == 2
     np.testing.assert_allclose(net.engine.get_params(), ref.engine.get_params(), rtol=0, atol=1e-4)
+
+
+@needs_persistent
+def test_async_train_repeats_both_steps_when_the_one_in_flight_was_void_too(tmp_path, monkeypatch, caplog):
+    """What voids step N (a co-tenant, a placement) is still there when step N+1 is enqueued - the host learns about N
+    one call later.  With the BPTT fault injected across two train() calls both steps are void: the second call must
+    learn the fate of the step in flight (nasr_settle_token) before it enqueues anything, then repeat N and N+1 in order -
+    three calls leave three updates, like an undisturbed run, and the second call reports the repeat's values."""
+    import logging
+    cfgs = [Config(make_config(tmp_path, num_gpus='1', model_dir=str(tmp_path / ('w%d' % k))), True) for k in range(2)]
+    net, ref = [c.load_network(fortraining=True) for c in cfgs]
+    ref.engine.set_params(net.engine.get_params())
+    ds = DataSet(cfgs[0].train_input, cfgs[0])
+    b0 = ds.get_next_batch()
+    b1 = ds.get_next_batch() if ds.has_more_batches() else b0
+    want = [ref.train(*b) for b in (b0, b1, b0)]
+    monkeypatch.setenv('NASR_PERSIST_FAULT', '2')
+    monkeypatch.setenv('NASR_PERSIST_FAULT_KERNEL', 'bwd')
+    got0 = net.train(*b0)                         # step 1: BPTT aborts, nobody knows yet
+    with caplog.at_level(logging.WARNING):
+        got1 = net.train(*b1)                     # step 2 runs into the same fault; then: settle 1, settle 2, redo 1, redo 2
+    monkeypatch.delenv('NASR_PERSIST_FAULT')
+    monkeypatch.delenv('NASR_PERSIST_FAULT_KERNEL')
+    msgs = [r.getMessage() for r in caplog.records]
+    assert any('step 1 was void' in m for m in msgs) and any('step 2 was void as well' in m for m in msgs)
+    assert net.engine.get_adam_state()[2] == 2 and net.engine.recurrence_mode == 'per-step'
+    assert float(got0[0]) == pytest.approx(float(want[0][0]), rel=2e-6)
+    assert float(got1[0]) == pytest.approx(float(want[1][0]), rel=2e-5)       # the repeat's loss: after step 1's update
+    got2 = net.train(*b0)
+    assert float(got2[0]) == pytest.approx(float(want[2][0]), rel=2e-4)
+    net.save_checkpoint()
+    assert net.global_step == 3 and net.engine.get_adam_state()[2] == 3
+    np.testing.assert_allclose(net.engine.get_params(), ref.engine.get_params(), rtol=0, atol=1e-4)
+
+
+def test_step_tokens_name_the_optimiser_steps(tmp_path):
+    """include/nasr.h: nasr_step_token / nasr_settle_token - a token per nasr_apply_adam, the last four remembered."""
+    from neuralasr_amd import _lib
+    cfg = Config(make_config(tmp_path, num_gpus='1'), True)
+    net = cfg.load_network(fortraining=True)
+    batch = DataSet(cfg.train_input, cfg).get_next_batch()
+    e = net.engine
+    assert e.step_token() == 0
+    toks = []
+    for _ in range(6):
+        net.begin_step(*batch)
+        toks.append(net._begun[1][1])
+        net.finish_step()
+    assert toks == [1, 2, 3, 4, 5, 6] and e.step_token() == 6
+    assert [e.settle_token(t) for t in toks[2:]] == [False] * 4
+    with pytest.raises(_lib.NasrError, match='older'):
+        e.settle_token(2)
+    with pytest.raises(_lib.NasrError, match='no such step'):
+        e.settle_token(7)

@@ -203,3 +203,47 @@ def test_prefetch_worker_stops_when_the_consumer_walks_away(tmp_path):
     while time.time() < deadline and any(t.name == 'nasr-prefetch' and t.is_alive() for t in threading.enumerate()):
         time.sleep(0.05)
     assert not any(t.name == 'nasr-prefetch' and t.is_alive() for t in threading.enumerate())
+
+
+def test_nested_prefetch_generators_restore_the_switch_interval(tmp_path):
+    """DataSet.prefetch lowers sys.setswitchinterval while a loader thread runs.  Two generators alive at once (train +
+    validation) closed in any order - or one of them abandoned - must leave the interval the process started with."""
+    import gc
+    import sys
+    samples = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sample_set')
+    lines = open(os.path.join(samples, 'toy.config')).read().replace('batch_size=2', 'batch_size=1')
+    cfgp = tmp_path / 'toy.config'
+    cfgp.write_text('\n'.join(('output=' + samples) if ln.startswith('output=') else ln for ln in lines.splitlines()) + '\n')
+    cfg = Config(str(cfgp), True)
+    start = sys.getswitchinterval()
+    a, b = DataSet(cfg.train_input, cfg).prefetch(depth=1), DataSet(cfg.test_input, cfg).prefetch(depth=1)
+    next(a)
+    assert sys.getswitchinterval() <= min(start, 2e-4)
+    next(b)
+    a.close()                                     # the first one in leaves first: the override must outlive it
+    assert sys.getswitchinterval() <= min(start, 2e-4)
+    del b                                         # abandoned, never closed
+    gc.collect()
+    assert sys.getswitchinterval() == start
+
+
+def test_train_loop_leaves_void_steps_out_of_its_means(tmp_path, caplog):
+    """A step whose forward pass was void reports NaN on every rank (HipNetwork repeats it one call later): the window's
+    means are taken over the steps that count, the log never shows `cost = nan`."""
+    text = open(os.path.join(SAMPLES, 'toy.config')).read().splitlines()
+    text = ['output=' + SAMPLES if l.startswith('output=') else l for l in text]
+    text = ['model_dir=' + str(tmp_path / 'm') if l.startswith('model_dir=') else l for l in text]
+    cfgp = tmp_path / 'c.config'
+    cfgp.write_text('\n'.join(text) + '\n')
+    cfg = Config(str(cfgp), True)
+
+    class VoidNet(StubNet):
+        def train(self, *a):
+            loss, ler = StubNet.train(self, *a)
+            return (np.float32('nan'), np.float32('nan')) if self.global_step == 1 else (loss, ler)
+    cfg.load_network = lambda fortraining=False: VoidNet(cfg, fortraining)
+    with caplog.at_level(logging.INFO, logger='NeuralASR'):
+        train_mod.train_model(DataSet(cfg.train_input, cfg), None, cfg)
+    steps = [r.getMessage() for r in caplog.records if r.getMessage().startswith('Step: ')]
+    assert steps[0].startswith('Step: 0002, cost = 4.0000, ler = 0.5000')       # step 1 (NaN) left out: mean of {4.0}
+    assert steps[1].startswith('Step: 0004, cost = 7.0000, ler = 0.5000')
