@@ -234,6 +234,75 @@ def cpu_baseline(spec, B, seed):
                              f'({int(seq_len.sum())} frames, {dt:.1f} s); Adam excluded'}
 
 
+def kernel_roofline(spec, B, T, phases, mode):
+    """The `roofline` object of a workload in compact form (the secondary entries of the line): the dominant recurrence
+    kernel's algorithmic bytes per launch (SURVEY.md §8d per-timestep figure x the timesteps one launch runs) over its live
+    launch duration against the HBM peak - or, for the wide kernels that keep a 2048-cell matrix resident, its three-product
+    fp16 MFMA work against the dense fp16 matrix peak (as the main line does for --workload deepspeech)."""
+    fb, bb = step_kernel_bytes(spec, B)
+    persistent, wide = mode == 'persistent', mode == 'wide-persistent'
+    spl = T if (persistent or wide) else 1
+    dpl = spec.dirs if wide else 1
+    fwd_us = phases['rec_fwd_ms'] * 1e3 / max(phases['rec_fwd_launches'], 1)
+    bwd_us = phases['rec_bwd_ms'] * 1e3 / max(phases['rec_bwd_launches'], 1)
+    dom_bwd = phases['rec_bwd_ms'] >= phases['rec_fwd_ms']
+    k_bytes, k_us = (bb * spl / dpl, bwd_us) if dom_bwd else (fb * spl / dpl, fwd_us)
+    fam = 'lstm_persist' if persistent else 'lstm_wide' if wide else 'lstm'
+    kname = f"{fam}_{'bwd' if dom_bwd else 'fwd'}{'' if (persistent or wide) else '_step'}_kernel"
+    achieved = k_bytes / (k_us * 1e-6) / 1e9
+    rl = {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'bytes_per_launch': k_bytes, 'us_per_launch': k_us,
+          'timesteps_per_launch': spl, 'fwd_step_us': fwd_us / spl, 'bwd_step_us': bwd_us / spl}
+    if wide:
+        bp = (B + 15) // 16 * 16
+        tf = 2.0 * bp * 2048 * 8192 * 3 * T / 1e12
+        rl.update({'bound': 'mfma', 'hbm_algorithmic_frac': rl['frac'], 'achieved': tf / (k_us * 1e-6), 'peak': 2500.0,
+                   'unit': 'TFLOP/s', 'frac': tf / (k_us * 1e-6) / 2500.0, 'mfma_products_per_fp32_product': 3})
+    return rl
+
+
+def measure_secondary(name, stream, device, steps=5, warmup=2):
+    """One more workload under the same clock, in the same process (N = 1): `steps` timed optimisation steps of the named
+    workload on a resident synthetic batch, bracketed by synchronisations like the main measurement."""
+    import torch
+    from neuralasr_amd.engine import Engine
+    spec, wname = workload_spec(name)
+    B, T = (32 if name == 'deepspeech' else 16), 500
+    eng = Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
+                 learning_rate=1e-4, device_id=device, stream=stream, pre=spec.pre, post=spec.post,
+                 relu_clip=spec.relu_clip, dropout=spec.dropout)
+    try:
+        eng.set_params(init_params(eng.tensors(), seed=1))
+        feats, seq_len, labels, label_len = synth_batch(spec, B, T, seed=1234)
+        eng.upload_batch(feats, seq_len, labels, label_len)
+        frames = eng.resident_frames()
+
+        def step():
+            eng.compute_grads()
+            eng.apply_adam(1.0)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        loss = eng.get_loss()
+        eng.set_profiling(True)
+        step()
+        phases = eng.phase_times()
+        eng.set_profiling(False)
+        aborts, _ = eng.persist_stats()
+        return {'config': {'workload': f'{wname}, F={spec.feature_size}, C={spec.num_classes}, batch {B} per GPU, T={T} frames'},
+                'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3, 'value': frames * steps / dt,
+                'unit': 'frames/s', 'dtype': 'f32', 'loss': loss, 'recurrence': eng.recurrence_mode, 'persist_aborts': aborts,
+                'roofline': kernel_roofline(spec, B, T, phases, eng.recurrence_mode),
+                'phases_ms': {k: round(v, 4) for k, v in phases.items() if k.endswith('_ms')}}
+    finally:
+        eng.close()
+
+
 PROFILE_FILES = {'pmc': 'pmc_traffic.json', 'stamps': 'persist_stamps.json'}
 
 
@@ -255,6 +324,7 @@ def main():
     ap.add_argument('--frames', type=int, default=500)
     ap.add_argument('--var-len', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads of the default run (literal, deepspeech)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--per-step', action='store_true', help='per-timestep launches (lstm.hip) instead of the persistent recurrence')
     ap.add_argument('--allreduce', default='auto', choices=['auto', 'bucketed', 'bucketed-eager', 'single', 'lib'],
@@ -605,6 +675,17 @@ def main():
                                         'timed steps exchange gradients (bucketed: per-layer buckets on a side stream '
                                         'under the rest of the backward pass, each released after the next persistent '
                                         'BPTT launch; bucketed-eager: released at once)'}
+        # BASELINE.json's other single-GPU shapes under the same clock (default run at N = 1 only): the literal 1x500
+        # BiLstmCTCNet (the parity shape, configs[1]'s class as the reference ships it) and configs[3]'s per-GPU workload
+        if (world == 1 and args.workload == 'bilstm3x500' and not args.var_len and not args.per_step and not args.no_secondary
+                and args.batch is None and args.frames == 500):
+            sec = {}
+            for name in ('literal', 'deepspeech'):
+                try:
+                    sec[name] = measure_secondary(name, stream, local)
+                except Exception as exc:      # noqa: BLE001 - a secondary workload never takes the line down
+                    sec[name] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+            out['secondary'] = sec
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, B, 1234)
         else:

@@ -147,14 +147,18 @@ __global__ __launch_bounds__(256) void scale_final_kernel(const float* __restric
 size_t tph_scale_ws_floats(int rows, int K) { return (size_t)((K + 63) / 64) * rows + (size_t)((rows + 63) / 64) * K; }
 
 // row_scale / row_inv [rows], col_scale / col_inv [K] (either pair may be NULL); ws: tph_scale_ws_floats(rows, K)
+void launch_tph_scales_batch(const TphScaleJob* jobs, int n, float* ws, hipStream_t st);
 void launch_tph_scales(const float* src, int rows, int K, int ld, float* row_scale, float* row_inv, float* col_scale,
                        float* col_inv, float* ws, hipStream_t st) {
+  if (col_scale) {        // one pass + ONE finishing launch for rows and columns (the batch kernels with a single job)
+    const TphScaleJob j{src, rows, K, ld, row_scale, row_inv, col_scale, col_inv};
+    launch_tph_scales_batch(&j, 1, ws, st);
+    return;
+  }
   dim3 grid((K + 63) / 64, (rows + 63) / 64);
   float* rp = row_scale ? ws : nullptr;
-  float* cp = col_scale ? ws + (size_t)grid.x * rows : nullptr;
-  hipLaunchKernelGGL(absmax_part_kernel, grid, dim3(256), 0, st, src, rows, K, ld, rp, cp);
+  hipLaunchKernelGGL(absmax_part_kernel, grid, dim3(256), 0, st, src, rows, K, ld, rp, (float*)nullptr);
   if (row_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((rows + 63) / 64), dim3(256), 0, st, rp, (int)grid.x, rows, row_scale, row_inv);
-  if (col_scale) hipLaunchKernelGGL(scale_final_kernel, dim3((K + 63) / 64), dim3(256), 0, st, cp, (int)grid.y, K, col_scale, col_inv);
 }
 
 // ---- the same for several (small) matrices in two launches: the weights, once per optimiser step
@@ -241,6 +245,17 @@ void launch_tph_scales_batch(const TphScaleJob* jobs, int n, float* ws, hipStrea
     hipLaunchKernelGGL(absmax_part_batch_kernel, dim3(gxm, gym, m), dim3(256), 0, st, sj);
     hipLaunchKernelGGL(scale_final_batch_kernel, dim3((nmax + 63) / 64, 2, m), dim3(256), 0, st, sj);
   }
+}
+
+void launch_tph_scales_from_parts(const float* rowpart, int nrp, int rows, float* row_scale, float* row_inv, const float* colpart,
+                                  int ncp, int K, float* col_scale, float* col_inv, hipStream_t st) {
+  ScaleJobs sj{};
+  sj.rows[0] = rows; sj.K[0] = K;
+  sj.rowpart[0] = row_scale ? const_cast<float*>(rowpart) : nullptr; sj.colpart[0] = col_scale ? const_cast<float*>(colpart) : nullptr;
+  sj.gx[0] = nrp; sj.gy[0] = ncp;            // scale_final_batch_kernel: parts per row line / per column line
+  sj.rs[0] = row_scale; sj.ri[0] = row_inv; sj.cs[0] = col_scale; sj.ci[0] = col_inv;
+  const int nmax = rows > K ? rows : K;
+  hipLaunchKernelGGL(scale_final_batch_kernel, dim3((nmax + 63) / 64, 2, 1), dim3(256), 0, st, sj);
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float v, int n) {

@@ -49,10 +49,13 @@ void launch_tph_scales(const float* src, int rows, int K, int ld, float* row_sca
                        float* col_inv, float* ws, hipStream_t st);
 // several matrices in two launches (column scales always, row scales when row_scale != NULL); ws:
 // tph_scale_batch_ws_floats(jobs, n) floats
-constexpr int TPH_MAX_JOBS = 8;
+constexpr int TPH_MAX_JOBS = 16;
 struct TphScaleJob { const float* src; int rows, K, ld; float *row_scale, *row_inv, *col_scale, *col_inv; };
 size_t tph_scale_batch_ws_floats(const TphScaleJob* jobs, int n);
 void launch_tph_scales_batch(const TphScaleJob* jobs, int n, float* ws, hipStream_t st);
+// scales from partial maxima somebody else took: rowpart [nrp][rows], colpart [ncp][K] (either pair may be NULL), one launch
+void launch_tph_scales_from_parts(const float* rowpart, int nrp, int rows, float* row_scale, float* row_inv, const float* colpart,
+                                  int ncp, int K, float* col_scale, float* col_inv, hipStream_t st);
 void launch_fill(float* p, float v, int n, hipStream_t st);
 // one pass over src [rows][K]: tpN = planes of src (scale per src row: row_scale[] or the constant rs), tpT = planes of its
 // transpose (scale per src column: col_scale[] or cs); either may be NULL; colpart (or NULL): tp_split2_parts(rows) x K
@@ -115,6 +118,8 @@ struct PersistCtl {            // device words, zeroed before every launch
 bool persist_supported(int Hp);
 size_t persist_image_floats(int Hp, bool bwd);   // floats of one direction's operand image
 size_t persist_xch_floats(int Hp);               // floats of the exchange buffer (shared by forward and BPTT)
+size_t persist_hx_bytes(int Hp);                 // its head, the forward kernel's h buffers: cleared before every forward launch
+size_t persist_px_bytes();                       // the BPTT kernel's partial-sum buffers: cleared before every BPTT launch
 hipError_t persist_prepare();                    // once per process: raise the kernels' dynamic-LDS limit
 // all n (layer, direction) matrices in one launch: matrix k is P + offs[k], its images Upf + k*image_floats(fwd) / Upb + k*...(bwd)
 constexpr int PERSIST_MAX_MATS = 16;
@@ -127,10 +132,14 @@ void launch_repack_persist(const float* P, const int64_t* offs, int n, float* Up
 // cinv (or NULL): [D][4*Hp] inverse column scales of this layer's matrices = the fp16 form of the forward image
 void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* cinv, float* gates, float* cbuf,
                              float* out, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky, float* fault,
-                             float forget_bias, hipStream_t st, bool ctl_zeroed = false);   // ctl_zeroed: the caller cleared *ctl
+                             float forget_bias, hipStream_t st, bool ctl_zeroed = false);   // ctl_zeroed: the caller cleared *ctl AND the first persist_hx_bytes of xch
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
-                             float* fault, hipStream_t st, bool ctl_zeroed = false);
+                             float* fault, hipStream_t st, bool ctl_zeroed = false, float* rowpart = nullptr,
+                             float* colpart = nullptr);   // ctl_zeroed: the caller cleared *ctl AND persist_px_bytes of xch
+// rowpart [D*32][T*Bp], colpart [8/D][D*4Hp] (or NULL): partial maxima of |dG| per frame row / per gate column, written by the
+// kernel's memory wave; launch_tph_scales_from_parts turns them into operand scales (persist_dgmax_floats sizes both)
+size_t persist_dgmax_floats(int T, int Bp, int Hp, int D);
 
 // ---- wide persistent forward recurrence (lstm_wide.hip): Hp = 2048, one launch per direction over all 256 CUs ----
 struct WideCtl {               // device words, zeroed before every launch

@@ -41,6 +41,16 @@
 #define NASR_PSTAMP 0   // 1: wave 0 of one workgroup accumulates s_memtime deltas per phase into PersistCtl::pad (tools/persistbench)
 #endif
 
+#ifndef NASR_FWD_EPOCH
+#define NASR_FWD_EPOCH 1   // forward hand-off: h words carry an epoch bit, consumers poll the payload itself (0: flag, then payload)
+#endif
+#ifndef NASR_BWD_EPOCH
+#define NASR_BWD_EPOCH 1   // BPTT hand-off: every partial sum carries an epoch bit in its last mantissa bit, consumers poll the sums
+#endif
+#ifndef NASR_EP_DELAY
+#define NASR_EP_DELAY 0    // s_sleep units between "this CU has published" and the first load of the others' h
+#endif
+
 namespace nasr {
 
 namespace {
@@ -122,6 +132,7 @@ __device__ __forceinline__ bool join_group(PersistCtl* ctl, unsigned* sticky, fl
     info[2] = 0;
     info[3] = 0;
     info[4] = 0;
+    info[5] = 0;
   }
   __syncthreads();
   xcc = info[0];
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
   constexpr int KW = 8 * NU;                 // units (= MFMAs) per wave
   constexpr int NCH = 2 * NU;                // 16-byte chunks (4 units x 1 utterance) per wave and utterance
   constexpr int NJ = (NCH + 15) / 16;        // 16-byte loads per lane
+  constexpr bool EP = F16 && NASR_FWD_EPOCH;  // hand-off validated by the payload's own epoch bits
   float* red = lds + LDS_RED;
   float* side = lds + LDS_SIDE;
   float* xgb = lds + LDS_XGB;
@@ -310,6 +322,8 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
   bool aborted = false;
   Stamps stp;
   stp.start(w == 0);
+  // epoch of the use of exchange buffer (s & 1) that step s of round rd is: uses alternate 1, 0, 1, ... from a cleared buffer
+  auto epoch_of = [&](int rd, int s) -> unsigned { return (unsigned)(rd * ((T + 1 - (s & 1)) >> 1) + (s >> 1) + 1) & 1u; };
 
   for (int rd = 0; rd < gm.rounds; ++rd) {
     const int b0 = (rd * NGD + grp) * gm.ub;
@@ -351,15 +365,60 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
       stp.mark(0);
       bool ok = true;
       if (w < 4) {
-        // 1. the 8 producers of this wave's K quarter have published h_{s-1} (and finished with h_{s-2})
-        ok = poll_ge(gflag + w * 8 + (lane & 7), lane < 8, tagbase + (unsigned)s) && !(s == gm.inject && member == 0);
-        stp.mark(1);
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 P[NJ];
 #pragma unroll
         for (int i = 0; i < NJ; ++i) P[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (EP) {
+          // 1+2. ONE round trip: every published word carries the epoch of its buffer's current use in bit 30 (a bit the
+          // scaled low part of h never sets, see the cell update), so the payload loads themselves say whether the 8
+          // producers of this wave's K quarter have published h_{s-1}.  A stale word (a producer that is late) is loaded
+          // again by its own lane only.  The previous use of the buffer (h_{s-3}) has the other epoch; nobody can be a
+          // whole use ahead, because publishing h_{s+1} takes everybody's h_s.
+          // Step 0 of a later round reuses the buffers of the round before: there (only) the flags are the barrier.
+          if (s == 0 && rd > 0) ok = poll_ge(gflag + w * 8 + (lane & 7), lane < 8, tagbase);
+          if (s == gm.inject && member == 0) ok = false;
+          stp.mark(1);
+          if (s > 0 && ok) {
+            if (w > 0) {   // this CU's cell wave has published h_{s-1}: the others have, or are about to
+              const unsigned want = tagbase + (unsigned)s;
+              for (unsigned n = 0; n < (1u << 26) && (int)(*(lds_vu32*)(info + 5) - want) < 0; ++n) __builtin_amdgcn_s_sleep(1);
+            }
+            if (NASR_EP_DELAY) __builtin_amdgcn_s_sleep(NASR_EP_DELAY);
+            const float* src = ghx + (size_t)((s - 1) & 1) * Hp * 4 + ((size_t)w * KW * 4 + (size_t)lane * 4);
+            const unsigned eexp = epoch_of(rd, s - 1) << 30;
+            const bool has0 = NCH >= 16 || lane < 4 * NCH, has1 = NJ == 2 && lane < 4 * (NCH - 16);
+            bool need = true;
+            ok = false;
+            for (unsigned n = 0; n < SPIN_BUDGET; ++n) {
+              if (need) {
+                if (has0) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(P[0]) : "v"(src) : "memory");
+                if constexpr (NJ == 2)
+                  if (has1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024 sc1" : "=&v"(P[NJ - 1]) : "v"(src) : "memory");
+              }
+              if constexpr (NJ == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(P[0]), "+v"(P[NJ - 1]) : : "memory");
+              else asm volatile("s_waitcnt vmcnt(0)" : "+v"(P[0]) : : "memory");
+              unsigned bad = 0;
+              if (has0)
+                bad |= (__float_as_uint(P[0][0]) ^ eexp) | (__float_as_uint(P[0][1]) ^ eexp) | (__float_as_uint(P[0][2]) ^ eexp) |
+                       (__float_as_uint(P[0][3]) ^ eexp);
+              if constexpr (NJ == 2)
+                if (has1)
+                  bad |= (__float_as_uint(P[NJ - 1][0]) ^ eexp) | (__float_as_uint(P[NJ - 1][1]) ^ eexp) |
+                         (__float_as_uint(P[NJ - 1][2]) ^ eexp) | (__float_as_uint(P[NJ - 1][3]) ^ eexp);
+              need = (bad & 0x40000000u) != 0;
+              if (!__any(need)) { ok = true; break; }
+#if NASR_PSTAMP
+              if (stp.on) stp.acc[11] += 1;      // extra attempts of wave 0
+#endif
+            }
+          }
+        } else {
+        // 1. the 8 producers of this wave's K quarter have published h_{s-1} (and finished with h_{s-2})
+        ok = poll_ge(gflag + w * 8 + (lane & 7), lane < 8, tagbase + (unsigned)s) && !(s == gm.inject && member == 0);
+        stp.mark(1);
         if (s > 0 && ok) {
           // 2. h_{s-1} of this K quarter: chunk = (unit/4)*4 + utterance, 16 B = 4 consecutive units
           const float* src = ghx + (size_t)((s - 1) & 1) * Hp * 4 + ((size_t)w * KW * 4 + (size_t)lane * 4);
@@ -378,6 +437,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
               asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(P[0]) : "v"(src) : "memory");
           }
         }
+        }
         if (w == 0 && lane == 0) *(lds_vu32*)(info + 4) = tagbase + (unsigned)s + 1u;   // MFMA phase starts (ds_write)
         stp.mark(2);
         if (s > 0 && ok) {
@@ -394,7 +454,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
               const u2 lo = {__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u)};
               const u2 hi = {__builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
               a1[i] = __builtin_bit_cast(h4, lo);
-              a2[i] = __builtin_bit_cast(h4, hi);
+              a2[i] = __builtin_bit_cast(h4, EP ? (u2){hi[0] & 0xBFFFBFFFu, hi[1] & 0xBFFFBFFFu} : hi);
             }
             static_for<0, NCH>([&](auto bbc) {
               constexpr int bb = decltype(bbc)::value;
@@ -412,6 +472,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
             });
           }
         }
+        if constexpr (EP) acc[0] *= 8.f;          // the low parts travel as h2 / 8 (exact): see the cell update
         f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         if constexpr (F16) sum *= oscale;
         float* rw = red + ((par * 4 + w) * 4) * 64 + lane;
@@ -467,9 +528,12 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
             // group (32 CUs x 4 waves redid these five operations per value on their MFMA chain): same arithmetic, same bits
             const float v = h * 16384.f;
             const _Float16 h1 = (_Float16)v;
-            const _Float16 h2 = (_Float16)(v - (float)h1);
+            // EP: the low part as (v - h1) / 8: |v - h1| <= 4, so its fp16 exponent field stays below 16 and bit 14 of the
+            // half - bit 30 of the word - is free for the epoch of this use of the buffer (the consumers multiply the
+            // h2 U1 product by 8; both scalings are exact)
+            const _Float16 h2 = (_Float16)(EP ? (v - (float)h1) * 0.125f : (v - (float)h1));
             const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, h1) |
-                                ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+                                ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16) | (EP ? epoch_of(rd, s) << 30 : 0u);
             ghx[(size_t)par * Hp * 4 + hidx] = __uint_as_float(pk);
           } else {
             ghx[(size_t)par * Hp * 4 + hidx] = h;          // plain store: lands in this XCD's L2
@@ -479,9 +543,14 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_fwd_kernel(
           *reinterpret_cast<float2*>(sp + 4) = make_float2(c, h);
         }
         stp.mark(5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and is acknowledged before the flag goes out
+        if constexpr (EP) {
+          // no acknowledgement to wait for: the words validate themselves.  The other waves of this CU start loading.
+          if (lane == 0) *(lds_vu32*)(info + 5) = tagbase + (unsigned)s + 1u;
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and is acknowledged before the flag goes out
+        }
         stp.mark(6);
-        if (lane == 0) *(ctl->flags + xcc * 128 + member) = tagbase + (unsigned)s + 1u;
+        if (lane == 0) *(ctl->flags + xcc * 128 + member) = tagbase + (unsigned)s + 1u;   // (EP: the round barrier only)
       }
       if (abort_word) { aborted = true; break; }
     }
@@ -499,7 +568,11 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
     const float* __restrict__ Upb, const float* __restrict__ gates, float* dgbuf, const float* __restrict__ cbuf,
     const float* __restrict__ dout, const int* __restrict__ seq_len,
     float* px,                      // [8 groups][2 parity][32 consumers][32 producers][16 units][4 utterances]
-    PersistCtl* ctl, unsigned* sticky, PersistGeom gm) {
+    PersistCtl* ctl, unsigned* sticky, PersistGeom gm,
+    // (or NULL) largest |dG| of every frame row over this CU's gate columns [D*32 parts][T*Bp], and of every gate column
+    // over this group's utterances [8/D parts][D*4Hp]: the partial maxima behind the operand scales of the GEMMs that
+    // read dG (gemm_tph.hip), taken by the memory wave from the values it stores anyway - no pass over dG afterwards
+    float* __restrict__ rowpart, float* __restrict__ colpart) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KW = 8 * NU;                  // output units per wave
   constexpr int NOG = (KW + 63) / 64;         // 64-unit output groups per wave
@@ -533,6 +606,13 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
   bool aborted = false;
   Stamps stp;
   stp.start(w == 0);
+  constexpr bool EP = NASR_BWD_EPOCH != 0;
+  f32x4 cmax = (f32x4){0.f, 0.f, 0.f, 0.f};   // memory wave: running column maxima of this lane's (unit, utterance slot)
+  // epoch of the use of exchange buffer (k & 1) that step k of round rd is (uses alternate 1, 0, 1, ... from a cleared buffer)
+  // (the rounds a group runs come first - b0 grows with rd - so rd counts its uses.  The buffer is CLEARED before every
+  //  launch: the bit pattern the sums carry is then a function of the launch's shape alone, and two runs of the same
+  //  step give the same bits)
+  auto epoch_of = [&](int rd, int k) -> unsigned { return (unsigned)(rd * ((T + 1 - (k & 1)) >> 1) + (k >> 1) + 1) & 1u; };
 
   for (int rd = 0; rd < gm.rounds; ++rd) {
     const int b0 = (rd * NGD + grp) * gm.ub;
@@ -564,12 +644,24 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
       *reinterpret_cast<f32x4*>(dst + 4) = pb;
     };
     auto store_dg = [&](int k) {    // memory wave: frame-indexed dG of step k (zero at masked frames) from the A image
+      float m = 0.f;
+      unsigned row = 0;
       if (rowok) {
         const int s = T - 1 - k;
         const float* ad = adg + (k & 1) * 256 + 16 * u + q;
         const f32x4 dg = (f32x4){ad[0], ad[4], ad[8], ad[12]};
-        const unsigned row = (unsigned)(((s < len) ? (d ? (len - 1 - s) : s) : s) * Bp + b);
+        row = (unsigned)(((s < len) ? (d ? (len - 1 - s) : s) : s) * Bp + b);
         *reinterpret_cast<f32x4*>(dgbuf + (row * (unsigned)DN + (unsigned)(d * N4 + 4 * j))) = dg;
+        const f32x4 ab = (f32x4){fabsf(dg.x), fabsf(dg.y), fabsf(dg.z), fabsf(dg.w)};
+        cmax = (f32x4){fmaxf(cmax.x, ab.x), fmaxf(cmax.y, ab.y), fmaxf(cmax.z, ab.z), fmaxf(cmax.w, ab.w)};
+        m = fmaxf(fmaxf(ab.x, ab.y), fmaxf(ab.z, ab.w));
+      }
+      if (rowpart) {   // max over the CU's units of this utterance slot: lanes 4u + q, u = 0..15 (order-independent: exact)
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x124, 0xf, 0xf, false)));   // row_ror:4
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x128, 0xf, 0xf, false)));   // row_ror:8
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < 4 && rowok) rowpart[(size_t)(d * 32 + (int)member) * ((size_t)T * Bp) + row] = m;
       }
     };
     if (w == 4) {
@@ -584,24 +676,28 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
       if (w == 0) {
         // 1. every wave of every producer has published its partial sums of step k-1
         bool ok = false;
-        {
+        if (!EP || (k == 0 && rd > 0)) {   // (EP: the flags are only the barrier between rounds, which reuse the buffers)
           const unsigned want = tagbase + (unsigned)k;
           for (unsigned n = 0; n < SPIN_BUDGET && !ok; ++n) {
             const unsigned v0 = __hip_atomic_load(gflag + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned v1 = __hip_atomic_load(gflag + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = __all((int)(v0 - want) >= 0 && (int)(v1 - want) >= 0);
           }
-          if (k == gm.inject && member == 0) ok = false;
+        } else {
+          ok = true;
         }
+        if (k == gm.inject && member == 0) ok = false;
         stp.mark(1);
         const bool valid = rowok && s < len;
         const float* pf = pfb + (par * 64 + lane) * 8;
         const f32x4 a = *reinterpret_cast<const f32x4*>(pf);
         const f32x4 o = *reinterpret_cast<const f32x4*>(pf + 4);
         float dhs = o.z;
-        if (k > 0 && ok && lane_ok) {
+        if (k > 0 && ok) {
           const float* src = gpx + ((size_t)(((k - 1) & 1) * 32 + member) * 32) * 64 + lane;
           float pv[32];
+#pragma unroll
+          for (int p = 0; p < 32; ++p) pv[p] = 0.f;
 #define NASR_LD8(g8)                                                                                               \
   asm volatile(                                                                                                    \
       "global_load_dword %0, %8, off sc1\n\tglobal_load_dword %1, %8, off offset:256 sc1\n\t"                       \
@@ -612,25 +708,57 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
         "=&v"(pv[g8 + 5]), "=&v"(pv[g8 + 6]), "=&v"(pv[g8 + 7])                                                    \
       : "v"(src + (size_t)(g8) * 64)                                                                               \
       : "memory")
-          NASR_LD8(0); NASR_LD8(8); NASR_LD8(16); NASR_LD8(24);
-#undef NASR_LD8
-          // one wait for all 32 loads; naming every destination keeps hipcc from touching them before it
-          asm volatile("s_waitcnt vmcnt(0)"
-                       : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
-                         "+v"(pv[7]), "+v"(pv[8]), "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]),
-                         "+v"(pv[14]), "+v"(pv[15])
-                       :
-                       : "memory");
-          asm volatile(""
-                       : "+v"(pv[16]), "+v"(pv[17]), "+v"(pv[18]), "+v"(pv[19]), "+v"(pv[20]), "+v"(pv[21]), "+v"(pv[22]),
-                         "+v"(pv[23]), "+v"(pv[24]), "+v"(pv[25]), "+v"(pv[26]), "+v"(pv[27]), "+v"(pv[28]), "+v"(pv[29]),
-                         "+v"(pv[30]), "+v"(pv[31])
-                       :
-                       : "memory");
-          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+          // EP: the sums themselves say whether they are those of step k-1 - bit 0 of every word is the epoch of this use
+          // of the buffer; a lane that finds a stale word loads its 32 again (one round trip when everybody is on time,
+          // and no acknowledgement wait or flag on the producers' side)
+          const unsigned eexp = epoch_of(rd, k - 1);
+          bool need = lane_ok;
+          bool got = false;
+          for (unsigned n = 0; n < (EP ? SPIN_BUDGET : 1u); ++n) {
+            if (need) { NASR_LD8(0); NASR_LD8(8); NASR_LD8(16); NASR_LD8(24); }
+            // one wait for all 32 loads; naming every destination keeps hipcc from touching them before it
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
+                           "+v"(pv[7]), "+v"(pv[8]), "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]),
+                           "+v"(pv[14]), "+v"(pv[15])
+                         :
+                         : "memory");
+            asm volatile(""
+                         : "+v"(pv[16]), "+v"(pv[17]), "+v"(pv[18]), "+v"(pv[19]), "+v"(pv[20]), "+v"(pv[21]), "+v"(pv[22]),
+                           "+v"(pv[23]), "+v"(pv[24]), "+v"(pv[25]), "+v"(pv[26]), "+v"(pv[27]), "+v"(pv[28]), "+v"(pv[29]),
+                           "+v"(pv[30]), "+v"(pv[31])
+                         :
+                         : "memory");
+            if constexpr (EP) {
+              unsigned bad;                   // bit 0: some word of this lane is not of epoch eexp (wave-uniform branch)
+              if (eexp) {
+                unsigned a_ = 1u;
 #pragma unroll
-          for (int p = 0; p < 32; p += 4) { s0 += pv[p]; s1 += pv[p + 1]; s2 += pv[p + 2]; s3 += pv[p + 3]; }
-          dhs += (s0 + s1) + (s2 + s3);
+                for (int p = 0; p < 32; ++p) a_ &= __float_as_uint(pv[p]);
+                bad = ~a_;
+              } else {
+                unsigned o_ = 0u;
+#pragma unroll
+                for (int p = 0; p < 32; ++p) o_ |= __float_as_uint(pv[p]);
+                bad = o_;
+              }
+              need = lane_ok && (bad & 1u) != 0;
+              if (!__any(need)) { got = true; break; }
+#if NASR_PSTAMP
+              if (stp.on) stp.acc[11] += 1;      // extra attempts
+#endif
+            } else {
+              got = true;
+            }
+          }
+#undef NASR_LD8
+          if (!got) ok = false;
+          if (lane_ok) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 32; p += 4) { s0 += pv[p]; s1 += pv[p + 1]; s2 += pv[p + 2]; s3 += pv[p + 3]; }
+            dhs += (s0 + s1) + (s2 + s3);
+          }
         }
         stp.mark(2);
         // 2. gate derivatives of this CU's cells
@@ -680,9 +808,14 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
         });
       });
       // 4. hand the partial rows to their consumers: unit k' -> consumer k'/NU, row element 4*(k'%NU) + utt
+      const unsigned eb = epoch_of(rd, k);
 #pragma unroll
       for (int og = 0; og < NOG; ++og) {
-        const f32x4 sum = acc[og][0] + acc[og][1];
+        f32x4 sum = acc[og][0] + acc[og][1];
+        if constexpr (EP) {   // the last mantissa bit of every sum = the epoch of this use of the buffer
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sum[i] = __uint_as_float((__float_as_uint(sum[i]) & ~1u) | eb);
+        }
         const int kl = og * 64 + lane;
         if (kl < KW) {
           const int kk = w * KW + kl;
@@ -691,13 +824,23 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
         }
       }
       stp.mark(5);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!EP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stp.mark(6);
       if (lane == 0) *(ctl->flags + xcc * 128 + member * 4 + w) = tagbase + (unsigned)k + 1u;
       if (abort_word) { aborted = true; break; }
     }
     if (aborted) break;
     __syncthreads();                  // pfb / adg are reused by the next round
+  }
+  if (w == 4 && colpart) {   // column maxima of this group's utterances: over the 4 utterance slots (lanes 4u + q), then out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = cmax[i];
+      v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+      v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+      cmax[i] = v;
+    }
+    if (q == 0 && lane_ok) *reinterpret_cast<f32x4*>(colpart + ((size_t)grp * DN + (size_t)(d * N4 + 4 * j))) = cmax;
   }
   stp.flush(ctl, xcc * 32 + member, xcc == 0 && member == 0);
   if (aborted && tid == 0) raise_error(ctl, sticky, gm.fault, 1u);
@@ -723,6 +866,12 @@ static PersistGeom make_geom(const LstmDims& dm, bool bwd) {
   g.fault = nullptr;
   return g;
 }
+
+size_t persist_dgmax_floats(int T, int Bp, int Hp, int D) { return (size_t)D * 32 * T * Bp + (size_t)(8 / D) * D * 4 * Hp; }
+
+size_t persist_px_bytes() { return (size_t)8 * 2 * 32 * 32 * 64 * sizeof(float); }   // the BPTT kernel's exchange buffer
+
+size_t persist_hx_bytes(int Hp) { return (size_t)8 * 2 * Hp * 4 * sizeof(float); }   // the forward kernel's part of xch
 
 size_t persist_xch_floats(int Hp) {
   const size_t f = (size_t)8 * 2 * Hp * 4, b = (size_t)8 * 2 * 32 * 32 * 64;
@@ -752,6 +901,8 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* 
   PersistGeom gm = make_geom(dm, false);
   gm.fault = fault;
   if (!ctl_zeroed) (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
+  // epoch-validated hand-off: the exchange buffers start from epoch 0 (ctl_zeroed: the caller cleared them with *ctl)
+  if (NASR_FWD_EPOCH && cinv && !ctl_zeroed) (void)hipMemsetAsync(xch, 0, persist_hx_bytes(dm.Hp), st);
   dim3 grid(256), block(320);
 #define NASR_PF(NUV)                                                                                                  \
   if (cinv)                                                                                                           \
@@ -775,14 +926,16 @@ void launch_lstm_persist_fwd(const LstmDims& dm, const float* Upf, const float* 
 
 void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* gates, float* dgbuf, const float* cbuf,
                              const float* dout, const int* seq_len, float* xch, PersistCtl* ctl, unsigned* sticky,
-                             float* fault, hipStream_t st, bool ctl_zeroed) {
+                             float* fault, hipStream_t st, bool ctl_zeroed, float* rowpart, float* colpart) {
   PersistGeom gm = make_geom(dm, true);
   gm.fault = fault;
   if (!ctl_zeroed) (void)hipMemsetAsync(ctl, 0, sizeof(PersistCtl), st);
+  // epoch-validated hand-off: the exchange buffer starts from epoch 0 (ctl_zeroed: the caller cleared it with *ctl)
+  if (NASR_BWD_EPOCH && !ctl_zeroed) (void)hipMemsetAsync(xch, 0, persist_px_bytes(), st);
   dim3 grid(256), block(320);
 #define NASR_PB(NUV)                                                                                                   \
   hipLaunchKernelGGL((lstm_persist_bwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upb, gates, dgbuf, cbuf, dout, \
-                     seq_len, xch, ctl, sticky, gm)
+                     seq_len, xch, ctl, sticky, gm, rowpart, colpart)
   switch (dm.Hp / 32) {
     case 2: NASR_PB(2); break;
     case 4: NASR_PB(4); break;

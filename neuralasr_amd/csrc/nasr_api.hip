@@ -132,7 +132,10 @@ struct nasr_ctx {
   bool rec_f16 = false;
   float *Ucs = nullptr, *Ucinv = nullptr;
   size_t imf = 0, imb = 0;             // floats per (layer, direction) image
-  float* xch = nullptr;                // exchange buffer
+  // the hand-offs validate themselves by epoch bits (lstm_persist.hip) and start from cleared buffers: one buffer per
+  // layer pass, all of a pass cleared in one go
+  float* xchf = nullptr;               // [L] h exchange buffers of the forward launches (persist_hx_bytes each)
+  float* xchb = nullptr;               // [L] partial-sum exchange buffers of the BPTT launches (persist_px_bytes each)
   PersistCtl* pctl = nullptr;
   // Wide persistent FORWARD recurrence (lstm_wide.hip): Hp = 2048 (DeepSpeech's cell count), one launch per direction
   // with U resident in the registers of all 256 CUs; the BPTT of such a layer stays on the per-step kernels.  NASR_WIDE=0
@@ -196,6 +199,8 @@ struct nasr_ctx {
   std::vector<SV> sc_dr, sc_dc;              // dense W[i]
   DevBuf scws;                               // partial maxima (launch_tph_scales)
   int gttp_layer = -1;                       // layer whose transposed dG planes gemm_dx has just written (fused split)
+  int dgmax_layer = -1;                      // layer whose |dG| maxima the persistent BPTT kernel has left in `dgmax`
+  DevBuf dgmax;                              // [D*32][R] row parts | [8/D][D*N4] column parts (persist_dgmax_floats)
   float* Gbase = nullptr;                    // allocation behind G: [GRAD_HEAD floats, [0] = fault word][np_int gradients]
   // gradient buckets: (offset, count) in floats from Gbase, in the order backward() completes them; one event each
   std::vector<std::pair<int64_t, int64_t>> buckets;
@@ -237,7 +242,9 @@ struct nasr_ctx {
   int32_t *seq_p = nullptr, *lablen_p = nullptr, *labels_p = nullptr, *cstart_p = nullptr, *cpos_p = nullptr,
           *rowmap_p = nullptr;
 
-  DevBuf XTP, X0TTP, OTTP0, OTTP1, GTP, GTTP;   // tiled-plane copies of activations / dG
+  DevBuf XTP, X0TTP, GTP, GTTP;   // tiled-plane copies of activations / dG
+  std::vector<DevBuf> OTT;        // per layer: planes of out[l] with the frame index as contraction index (weight gradients)
+  std::vector<char> ott_valid;    // ... written by the forward pass of this step already (together with the planes of layer l+1's input)
   DevBuf seqbuf, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, slabs, csws, amax, ids, lens,
       stage;
   std::vector<DevBuf> gates, outb, cbuf;
@@ -352,9 +359,9 @@ bool persist_census(nasr_ctx* h) {
     (void)hipMemcpyAsync(sq.p, two.data(), Bp * 4, hipMemcpyHostToDevice, h->st);
     const LstmDims dm{T, Bp, Bp, h->H, h->Hp, h->D};
     launch_lstm_persist_fwd(dm, h->Upf, h->rec_f16 ? h->Ucinv : nullptr, g.as<float>(), c.as<float>(), o.as<float>(),
-                            sq.as<int>(), h->xch, h->pctl, h->perr, nullptr, 1.f, h->st);
+                            sq.as<int>(), h->xchf, h->pctl, h->perr, nullptr, 1.f, h->st);
     launch_lstm_persist_bwd(dm, h->Upb, g.as<float>(), dg.as<float>(), c.as<float>(), o.as<float>(), sq.as<int>(),
-                            h->xch, h->pctl, h->perr, nullptr, h->st);
+                            h->xchb, h->pctl, h->perr, nullptr, h->st);
     ok = hipStreamSynchronize(h->st) == hipSuccess && hipGetLastError() == hipSuccess && *h->perr == 0;
   }
   for (DevBuf* b : {&g, &c, &o, &dg, &sq}) b->release();
@@ -611,13 +618,33 @@ int build_layout(nasr_ctx* h) {
 
 int repack(nasr_ctx* h) {
   // only the operand images of the kernels in use (a mode switch calls repack again)
+  // scales of every matrix that needs them - recurrent matrices of the persistent / wide kernels, input and dense
+  // weights of the plane GEMMs - in ONE batch (two launches), then the images
+  std::vector<TphScaleJob> jobs;
+  if (h->persist && h->rec_f16)
+    for (size_t k = 0; k < h->off_u.size(); ++k)
+      jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, nullptr, nullptr, h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
+  if (!h->persist && h->wide)
+    for (size_t k = 0; k < h->off_u.size(); ++k)
+      jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, h->Urs + k * h->Hp, h->Urinv + k * h->Hp,
+                      h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
+  for (int l = 0; l < h->L; ++l) {
+    const bool back = l > 0 || h->npre > 0;
+    jobs.push_back({h->P + h->off_wx[l], h->Ip[l], h->D * h->N4, h->D * h->N4, back ? h->sc_wr[l].sp() : nullptr,
+                    back ? h->sc_wr[l].ip() : nullptr, h->sc_wc[l].sp(), h->sc_wc[l].ip()});
+  }
+  for (int i = 0; i < h->ndense; ++i) {
+    const bool back = i > 0 || h->npre == 0;
+    jobs.push_back({h->P + h->off_dw[i], h->dIp[i], h->dWp[i], h->dWp[i], back ? h->sc_dr[i].sp() : nullptr,
+                    back ? h->sc_dr[i].ip() : nullptr, h->sc_dc[i].sp(), h->sc_dc[i].ip()});
+  }
+  {
+    bool g2 = false;
+    if (!h->scws.ensure(tph_scale_batch_ws_floats(jobs.data(), (int)jobs.size()) * 4, &g2))
+      return h->fail(NASR_ERR_HIP, "allocation of the scale workspace failed");
+  }
+  launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
   if (h->persist) {
-    if (h->rec_f16) {   // column scales of every recurrent matrix (two launches), then the fp16 forward image
-      std::vector<TphScaleJob> jobs;
-      for (size_t k = 0; k < h->off_u.size(); ++k)
-        jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, nullptr, nullptr, h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
-      launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
-    }
     launch_repack_persist(h->P, h->off_u.data(), (int)h->off_u.size(), h->Upf, h->Upb, h->Hp,
                           h->rec_f16 ? h->Ucs : nullptr, h->st);
   } else {
@@ -628,46 +655,24 @@ int repack(nasr_ctx* h) {
           const size_t o = k * (size_t)h->Hp * h->N4;
           launch_repack_u(h->P + h->off_u[k], h->Uf + o, h->Ub + o, h->Hp, h->st);
         }
-    if (h->wide) {   // column scales of every recurrent matrix, then the fp16-plane images of the wide forward kernel
-      std::vector<TphScaleJob> jobs;
-      for (size_t k = 0; k < h->off_u.size(); ++k)
-        jobs.push_back({h->P + h->off_u[k], h->Hp, h->N4, h->N4, h->Urs + k * h->Hp, h->Urinv + k * h->Hp,
-                        h->Ucs + k * h->N4, h->Ucinv + k * h->N4});
-      launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
+    if (h->wide)    // the fp16-plane images of the wide kernels
       for (size_t k = 0; k < h->off_u.size(); ++k) {
         launch_repack_wide(h->P + h->off_u[k], h->Ucs + k * h->N4, h->Uw + k * wide_image_bytes(h->Hp), h->Hp, h->st);
         launch_repack_wide_bwd(h->P + h->off_u[k], h->Urs + k * h->Hp, h->Uwb + k * wide_image_bytes(h->Hp), h->Hp, h->st);
       }
-    }
   }
-  {
-    {   // scales of every weight matrix in two launches
-      std::vector<TphScaleJob> jobs;
-      for (int l = 0; l < h->L; ++l) {
-        const bool back = l > 0 || h->npre > 0;
-        jobs.push_back({h->P + h->off_wx[l], h->Ip[l], h->D * h->N4, h->D * h->N4, back ? h->sc_wr[l].sp() : nullptr,
-                        back ? h->sc_wr[l].ip() : nullptr, h->sc_wc[l].sp(), h->sc_wc[l].ip()});
-      }
-      for (int i = 0; i < h->ndense; ++i) {
-        const bool back = i > 0 || h->npre == 0;
-        jobs.push_back({h->P + h->off_dw[i], h->dIp[i], h->dWp[i], h->dWp[i], back ? h->sc_dr[i].sp() : nullptr,
-                        back ? h->sc_dr[i].ip() : nullptr, h->sc_dc[i].sp(), h->sc_dc[i].ip()});
-      }
-      launch_tph_scales_batch(jobs.data(), (int)jobs.size(), h->scws.as<float>(), h->st);
-    }
-    for (int l = 0; l < h->L; ++l) {
-      // forward operand = planes of Wx^T, input-gradient operand = planes of Wx: one pass where both are needed
-      const bool back = l > 0 || h->npre > 0;
-      const float* W = h->P + h->off_wx[l];
-      pl_split(W, back ? h->WbTP + h->off_wbtp[l] : nullptr, h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
-               h->D * h->N4, back ? h->sc_wr[l].sp() : nullptr, h->sc_wc[l].sp(), nullptr, h->st);
-    }
-    for (int i = 0; i < h->ndense; ++i) {
-      const bool back = i > 0 || h->npre == 0;   // the first pre stage reads the features: no gradient wrt its input
-      const float* W = h->P + h->off_dw[i];
-      pl_split(W, back ? h->DbTP + h->off_dbtp[i] : nullptr, h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i], h->dWp[i],
-               back ? h->sc_dr[i].sp() : nullptr, h->sc_dc[i].sp(), nullptr, h->st);
-    }
+  for (int l = 0; l < h->L; ++l) {
+    // forward operand = planes of Wx^T, input-gradient operand = planes of Wx: one pass where both are needed
+    const bool back = l > 0 || h->npre > 0;
+    const float* W = h->P + h->off_wx[l];
+    pl_split(W, back ? h->WbTP + h->off_wbtp[l] : nullptr, h->WfTP + h->off_wftp[l], h->Ip[l], h->D * h->N4,
+             h->D * h->N4, back ? h->sc_wr[l].sp() : nullptr, h->sc_wc[l].sp(), nullptr, h->st);
+  }
+  for (int i = 0; i < h->ndense; ++i) {
+    const bool back = i > 0 || h->npre == 0;   // the first pre stage reads the features: no gradient wrt its input
+    const float* W = h->P + h->off_dw[i];
+    pl_split(W, back ? h->DbTP + h->off_dbtp[i] : nullptr, h->DfTP + h->off_dftp[i], h->dIp[i], h->dWp[i], h->dWp[i],
+             back ? h->sc_dr[i].sp() : nullptr, h->sc_dc[i].sp(), nullptr, h->st);
   }
   HIPCHK(h, hipGetLastError());
   return NASR_OK;
@@ -706,14 +711,14 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   ok &= h->partial.ensure((size_t)2 * D * (Hp / 32) * Bp * Hp * 4, &grew);
   ok &= h->dcstate.ensure((size_t)2 * D * Bp * Hp * 4, &grew);
   ok &= h->dgbuf.ensure(R * D * N4 * 4, &grew);
+  if (h->Upf) ok &= h->dgmax.ensure(persist_dgmax_floats(T, Bp, Hp, D) * 4, &grew);
   {
     int ipmax = h->Fp, wmax = D * N4;
     for (int l = 0; l < h->L; ++l) ipmax = std::max(ipmax, h->Ip[l]);
     for (int i = 0; i < h->ndense; ++i) { ipmax = std::max(ipmax, h->dIp[i]); wmax = std::max(wmax, h->dWp[i]); }
     ok &= h->XTP.ensure(tph_bytes((int)R, ipmax), &grew);
     ok &= h->X0TTP.ensure(tph_bytes(h->Ip[0], (int)R), &grew);
-    ok &= h->OTTP0.ensure(tph_bytes(D * Hp, (int)R), &grew);
-    ok &= h->OTTP1.ensure(tph_bytes(D * Hp, (int)R), &grew);
+    for (int l = 0; l < h->L; ++l) ok &= h->OTT[l].ensure(tph_bytes(D * Hp, (int)R), &grew);
     ok &= h->GTP.ensure(tph_bytes((int)R, wmax), &grew);
     ok &= h->GTTP.ensure(tph_bytes(wmax, (int)R), &grew);
     if (h->ndense) ok &= h->DTP.ensure(tph_bytes(ipmax, (int)R), &grew);
@@ -1043,11 +1048,16 @@ int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
     if (!bwd)
       launch_lstm_persist_fwd(dm, h->Upf + k * h->imf, h->rec_f16 ? h->Ucinv + k * h->N4 : nullptr,
                               h->gates[l].as<float>(), h->cbuf[l].as<float>(),
-                              h->outb[l].as<float>(), h->seq_p, h->xch, h->pctl + 1 + l, h->perr, h->Gbase,
-                              h->cfg.forget_bias, st, true);
+                              h->outb[l].as<float>(), h->seq_p, h->xchf + (size_t)l * (persist_hx_bytes(h->Hp) / 4),
+                              h->pctl + 1 + l, h->perr, h->Gbase, h->cfg.forget_bias, st, true);
     else
+    {
       launch_lstm_persist_bwd(dm, h->Upb + k * h->imb, h->gates[l].as<float>(), dg_of(h, l), h->cbuf[l].as<float>(),
-                              dout_of(h, l), h->seq_p, h->xch, h->pctl + 1 + h->L + l, h->perr, h->Gbase, st, true);
+                              dout_of(h, l), h->seq_p, h->xchb + (size_t)l * (persist_px_bytes() / 4), h->pctl + 1 + h->L + l,
+                              h->perr, h->Gbase, st, true, h->dgmax.as<float>(),
+                              h->dgmax.as<float>() + (size_t)h->D * 32 * h->T * h->Bp);
+      h->dgmax_layer = l;
+    }
     h->persist_used = true;
     HIPCHK(h, hipGetLastError());
     return NASR_OK;
@@ -1107,6 +1117,19 @@ float* ensure_slabs(nasr_ctx* h, int split, int M, int N) {
   return h->slabs.as<float>();
 }
 
+// operand scales of layer l's dG (rows = frames: sc_gr, optional; columns = gates: sc_gc): from the maxima the persistent
+// BPTT kernel took while it stored dG, or by a pass over dG
+void dg_scales(nasr_ctx* h, int l, int R, bool rows, hipStream_t st) {
+  const int DN = h->D * h->N4;
+  if (h->dgmax_layer == l) {
+    const float* rp = h->dgmax.as<float>();
+    launch_tph_scales_from_parts(rp, h->D * 32, R, rows ? h->sc_gr.sp() : nullptr, rows ? h->sc_gr.ip() : nullptr,
+                                 rp + (size_t)h->D * 32 * R, 8 / h->D, DN, h->sc_gc.sp(), h->sc_gc.ip(), st);
+  } else {
+    pl_scales(h, dg_of(h, l), R, DN, DN, rows ? &h->sc_gr : nullptr, &h->sc_gc, st);
+  }
+}
+
 // input of LSTM layer l: the features, the last pre-dense stage's output, or the layer below
 inline const float* lstm_input(nasr_ctx* h, int l) {
   if (l > 0) return h->outb[l - 1].as<float>();
@@ -1117,7 +1140,12 @@ inline const float* lstm_input(nasr_ctx* h, int l) {
 void gemm_xproj(nasr_ctx* h, int l, int R, hipStream_t st) {
   const int D = h->D, N4 = h->N4, Ip = h->Ip[l];
   const ActScale as = lstm_in_scale(h, l);
-  pl_split(lstm_input(h, l), h->XTP.as<unsigned char>(), nullptr, R, Ip, Ip, as.rs, nullptr, nullptr, st);
+  // a training step wants the layer below's output a second time, with the frame index as contraction index (its own
+  // recurrent weight gradient and this layer's input weight gradient): both plane sets in this one pass over it
+  const bool both = l > 0 && h->cur && h->cur->has_labels;
+  pl_split(lstm_input(h, l), h->XTP.as<unsigned char>(), both ? h->OTT[l - 1].as<unsigned char>() : nullptr, R, Ip, Ip, as.rs,
+           both ? as.cs : nullptr, nullptr, st);
+  if (l > 0) h->ott_valid[l - 1] = both;
   GemmTPHDesc g{};
   g.A = h->XTP.as<unsigned char>(); g.B = h->WfTP + h->off_wftp[l]; g.C = h->gates[l].as<float>();
   g.M = R; g.N = D * N4; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * N4;
@@ -1132,7 +1160,7 @@ void gemm_dx(nasr_ctx* h, int l, int R, hipStream_t st) {
   const int D = h->D, N4 = h->N4;
   const float* A = dg_of(h, l);
   float* C = l > 0 ? dout_of(h, l - 1) : h->dYbuf[h->npre - 1].as<float>();
-  pl_scales(h, A, R, D * N4, D * N4, &h->sc_gr, &h->sc_gc, st);
+  dg_scales(h, l, R, true, st);
   pl_split(A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), R, D * N4, D * N4, h->sc_gr.sp(), h->sc_gc.sp(),
            h->csws.as<float>(), st);
   h->gttp_layer = l;   // weight_grads(l): transposed planes and column-sum partials of dG are there
@@ -1204,11 +1232,15 @@ int forward(nasr_ctx* h) {
   const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp;
   const int R = T * Bp;
   h->n_fwd_launch = 0;
+  std::fill(h->ott_valid.begin(), h->ott_valid.end(), 0);
   // the fault word of the pass that starts here (a training step or a forward-only call); what an unread earlier word
   // said is gone with it
   HIPCHK(h, hipMemsetAsync(h->Gbase, 0, GRAD_HEAD * 4, h->st));
   // the control blocks of this pass's persistent launches, cleared in one go (one per layer: run_steps)
-  if (h->persist) HIPCHK(h, hipMemsetAsync(h->pctl + 1, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
+  if (h->persist) {
+    HIPCHK(h, hipMemsetAsync(h->pctl + 1, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
+    HIPCHK(h, hipMemsetAsync(h->xchf, 0, (size_t)h->L * persist_hx_bytes(h->Hp), h->st));   // epoch 0 everywhere (lstm_persist.hip)
+  }
   for (int i = 0; i < h->npre; ++i) {
     PhaseScope ps(h, PH_XPROJ);
     int rc = dense_forward(h, i, i == 0 ? h->X0.as<float>() : h->Ybuf[i - 1].as<float>());
@@ -1298,23 +1330,25 @@ int weight_grads(nasr_ctx* h, int l) {
   float* dG = dg_of(h, l);
   hipStream_t ws = h->st;
   // tiled-plane copies with the frame index as contraction index (K = R)
-  unsigned char* tO[2] = {h->OTTP0.as<unsigned char>(), h->OTTP1.as<unsigned char>()};
   unsigned char* GT = h->GTTP.as<unsigned char>();
   const int nkb = (R + 15) / 16;
   // one pass over dG: its transposed planes + 64-row partial column sums (already there when gemm_dx(l) ran)
   if (h->gttp_layer != l) {
-    pl_scales(h, dG, R, D * N4, D * N4, nullptr, &h->sc_gc, ws);
+    dg_scales(h, l, R, false, ws);
     pl_split(dG, nullptr, GT, R, D * N4, D * N4, nullptr, h->sc_gc.sp(), h->csws.as<float>(), ws);
   }
   h->gttp_layer = -1;
   const ActScale ao = act_out(h), ai = lstm_in_scale(h, l);
-  if (l == h->L - 1) pl_split(h->outb[l].as<float>(), nullptr, tO[l & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
-  if (l > 0) pl_split(h->outb[l - 1].as<float>(), nullptr, tO[(l - 1) & 1], R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
+  for (int m = std::max(l - 1, 0); m <= l; ++m)     // out[l] (recurrent weight gradient), out[l-1] (input weight gradient)
+    if (!h->ott_valid[m]) {
+      pl_split(h->outb[m].as<float>(), nullptr, h->OTT[m].as<unsigned char>(), R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
+      h->ott_valid[m] = 1;
+    }
   if (l == 0 && h->npre)
     pl_split(lstm_input(h, l), nullptr, h->X0TTP.as<unsigned char>(), R, h->Ip[0], h->Ip[0], nullptr, ai.cs, nullptr, ws);
   {  // dWx = X^T dG
     GemmTPHDesc g{};
-    g.A = l == 0 ? h->X0TTP.as<unsigned char>() : tO[(l - 1) & 1];
+    g.A = l == 0 ? h->X0TTP.as<unsigned char>() : h->OTT[l - 1].as<unsigned char>();
     g.B = GT; g.C = h->G + h->off_wx[l];
     g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
     g.split_k = gemm_tph_pick_split(g.M, g.N, g.K);
@@ -1325,7 +1359,7 @@ int weight_grads(nasr_ctx* h, int l) {
   launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
   {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw); both directions in one launch
     GemmTPHDesc g{};
-    g.A = tO[l & 1]; g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
+    g.A = h->OTT[l].as<unsigned char>(); g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
     g.M = Hp; g.N = N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
     g.a_kshift = -Bp;
     g.nbatch = D;
@@ -1345,7 +1379,10 @@ int backward(nasr_ctx* h) {
   const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp;
   const int R = T * Bp, Rp = h->Tp * Bp;
   const bool sr = h->cfg.merge == NASR_MERGE_STACK_RESHAPE && D == 2;
-  if (h->persist) HIPCHK(h, hipMemsetAsync(h->pctl + 1 + h->L, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
+  if (h->persist) {
+    HIPCHK(h, hipMemsetAsync(h->pctl + 1 + h->L, 0, (size_t)h->L * sizeof(PersistCtl), h->st));
+    HIPCHK(h, hipMemsetAsync(h->xchb, 0, (size_t)h->L * persist_px_bytes(), h->st));   // epoch 0 everywhere (lstm_persist.hip)
+  }
   {
     PhaseScope ps(h, PH_PROJCTC);
     const CtcDims d = ctc_dims(h);
@@ -1386,6 +1423,7 @@ int backward(nasr_ctx* h) {
     if (rc) return rc;
   }
   h->n_bwd_launch = 0;
+  h->dgmax_layer = -1;
   for (int l = h->L - 1; l >= 0; --l) {
     const bool defer = (h->persist || h->wide) && h->bucket_defer;
     {
@@ -1599,7 +1637,8 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       const size_t nk = (size_t)h->L * h->D;
       if (persist_prepare() != hipSuccess || hipMalloc(&h->Upf, nk * h->imf * 4) != hipSuccess ||
           hipMalloc(&h->Upb, nk * h->imb * 4) != hipSuccess ||
-          hipMalloc(&h->xch, persist_xch_floats(h->Hp) * 4) != hipSuccess ||
+          hipMalloc(&h->xchf, (size_t)h->L * persist_hx_bytes(h->Hp)) != hipSuccess ||
+          hipMalloc(&h->xchb, (size_t)h->L * persist_px_bytes()) != hipSuccess ||
           hipMalloc(&h->pctl, (size_t)(1 + 2 * h->L) * sizeof(PersistCtl)) != hipSuccess ||   // [0] census, then one per layer pass
           hipHostMalloc(&h->perr, 64, hipHostMallocMapped) != hipSuccess)
         return bail(NASR_ERR_HIP, "allocation of the persistent-recurrence buffers failed");
@@ -1618,7 +1657,6 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
       }
       (void)hipMemsetAsync(h->Upf, 0, nk * h->imf * 4, h->st);
       (void)hipMemsetAsync(h->Upb, 0, nk * h->imb * 4, h->st);
-      (void)hipMemsetAsync(h->xch, 0, persist_xch_floats(h->Hp) * 4, h->st);
     }
   }
   {
@@ -1647,6 +1685,8 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
     }
   }
   h->gates.resize(h->L);
+  h->OTT.resize(h->L);
+  h->ott_valid.assign(h->L, 0);
   h->outb.resize(h->L);
   h->cbuf.resize(h->L);
   h->Ybuf.resize(h->ndense);
@@ -1695,7 +1735,7 @@ int nasr_destroy(nasr_handle h) {
   if (h->st) (void)hipStreamSynchronize(h->st);
   for (hipEvent_t e : h->ev_bucket) (void)hipEventDestroy(e);
   drop_graphs(h);
-  for (float* p : {h->P, h->M, h->V, h->Gbase, h->Uf, h->Ub, h->Upf, h->Upb, h->xch, h->Ucs, h->Ucinv})
+  for (float* p : {h->P, h->M, h->V, h->Gbase, h->Uf, h->Ub, h->Upf, h->Upb, h->xchf, h->xchb, h->Ucs, h->Ucinv})
     if (p) (void)hipFree(p);
   if (h->WfTP) (void)hipFree(h->WfTP);
   if (h->WbTP) (void)hipFree(h->WbTP);
@@ -1714,7 +1754,8 @@ int nasr_destroy(nasr_handle h) {
   if (h->wpart) (void)hipFree(h->wpart);
   if (h->wctl) (void)hipFree(h->wctl);
   if (h->perr) (void)hipHostFree(h->perr);
-  for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->OTTP0, &h->OTTP1, &h->GTP, &h->GTTP, &h->scws}) b->release();
+  for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->GTP, &h->GTTP, &h->scws}) b->release();
+  for (auto& b : h->OTT) b.release();
   for (nasr_ctx::SV* v : {&h->sc15, &h->sc_x0r, &h->sc_x0c, &h->sc_gr, &h->sc_gc}) v->release();
   for (auto* vec : {&h->sc_yr, &h->sc_yc, &h->sc_wr, &h->sc_wc, &h->sc_dr, &h->sc_dc})
     for (auto& v : *vec) v.release();
@@ -1740,7 +1781,7 @@ int nasr_destroy(nasr_handle h) {
   }
   for (DevBuf* b : {&h->seqbuf, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->logits, &h->logz,
                     &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->slabs,
-                    &h->csws, &h->amax, &h->ids, &h->lens, &h->stage})
+                    &h->csws, &h->amax, &h->ids, &h->lens, &h->stage, &h->dgmax})
     b->release();
   for (auto& b : h->gates) b.release();
   for (auto& b : h->outb) b.release();

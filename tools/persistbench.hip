@@ -124,8 +124,8 @@ int main(int argc, char** argv) {
     if (hc.pad[0] | hc.pad[1]) {
       printf("   wave 0 cycles/step: loop-top %.0f  poll %.0f  payload %.0f  mfma %.0f  barrier %.0f  cell %.0f  store-ack %.0f\n", hc.pad[0] / (double)T,
              hc.pad[1] / (double)T, hc.pad[2] / (double)T, hc.pad[3] / (double)T, hc.pad[4] / (double)T, hc.pad[5] / (double)T, hc.pad[6] / (double)T);
-      printf("   barrier arrival after wave 0 (cycles): w1 %.0f  w2 %.0f  w3 %.0f  mem %.0f\n", (int)hc.pad[7] / (double)T, (int)hc.pad[8] / (double)T,
-             (int)hc.pad[9] / (double)T, (int)hc.pad[10] / (double)T);
+      printf("   barrier arrival after wave 0 (cycles): w1 %.0f  w2 %.0f  w3 %.0f  mem %.0f   extra hand-off attempts of wave 0 per step %.3f\n", (int)hc.pad[7] / (double)T, (int)hc.pad[8] / (double)T,
+             (int)hc.pad[9] / (double)T, (int)hc.pad[10] / (double)T, hc.pad[11] / (double)T);
     }
 #if defined(NASR_PSTAMP) && NASR_PSTAMP
     {   // every workgroup's wave 0: the slowest chain sets the step; a phase that waits for others (poll) is shortest there
@@ -161,9 +161,9 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
     printf("backward: per-step %.3f us/step   persistent %.3f us/step (%.3f ms)   error word %u\n", bstep * 1000 / T, ms * 1000 / T, ms, hc.error);
     if (hc.pad[0] | hc.pad[1]) {
-      printf("   wave 0 cycles/step: tail+prefetch %.0f  poll %.0f  partial loads+sum %.0f  cell bwd %.0f  barrier %.0f  mfma+stores %.0f  store-ack %.0f\n",
+      printf("   wave 0 cycles/step: tail+prefetch %.0f  poll %.0f  partial loads+sum %.0f  cell bwd %.0f  barrier %.0f  mfma+stores %.0f  store-ack %.0f   extra hand-off attempts per step %.3f\n",
              hc.pad[0] / (double)T, hc.pad[1] / (double)T, hc.pad[2] / (double)T, hc.pad[3] / (double)T, hc.pad[4] / (double)T, hc.pad[5] / (double)T,
-             hc.pad[6] / (double)T);
+             hc.pad[6] / (double)T, hc.pad[11] / (double)T);
     }
 #if defined(NASR_PSTAMP) && NASR_PSTAMP
     {

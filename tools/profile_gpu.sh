@@ -11,10 +11,10 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 for WL in $WLS; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/stats_$WL.log" 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/fetch_$WL.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/write_$WL.log" 2>&1
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/mfma_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/mfma_$WL.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > "$OUT/stats_$WL.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/fetch_$WL.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/write_$WL.log" 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/mfma_$WL" -- python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/mfma_$WL.log" 2>&1
   cp "$OUT"/stats_$WL/*/*kernel_stats.csv "$OUT/${TAG}_${WL}_kernel_stats.csv"
   python3 "$ROOT/tools/pmc_summary.py" $WL "$OUT/fetch_$WL" "$OUT/write_$WL" "$OUT/pmc_traffic.json" "$OUT/mfma_$WL" > "$OUT/${TAG}_pmc_$WL.txt"
   # the raw counter tables are large: keep the summaries only
