@@ -184,7 +184,10 @@ int nasr_compute_grads(nasr_handle h);          /* forward+CTC+backward on the r
  * below), and makes the handle's stream wait for the last one: no host synchronisation.  The step's fault word travels
  * in the last bucket, so a void step (nasr_step_void) is void on every rank.  nasr_comm_mean averages a few host floats
  * over the ranks (the reduce_mean of loss / LER at tfnetwork.py:135-136); without a communicator it leaves them as
- * they are. */
+ * they are.  It runs on a communicator and a stream of its own (ncclCommSplit of the handle's communicator at
+ * nasr_comm_init), so it neither waits for the gradient buckets of a step in flight nor for the compute stream; with a
+ * librccl that has no ncclCommSplit it shares the gradient communicator and is executed behind the buckets issued
+ * before it (one communicator runs its collectives in issue order). */
 int nasr_comm_unique_id(void* id128);
 int nasr_comm_init(nasr_handle h, const void* id128, int rank, int nranks);
 int nasr_comm_size(nasr_handle h);
@@ -201,7 +204,12 @@ int64_t nasr_grad_device_count(nasr_handle h);
 int nasr_grad_bucket_count(nasr_handle h);
 int nasr_grad_bucket(nasr_handle h, int i, int64_t* offset, int64_t* count);
 int nasr_grad_bucket_wait(nasr_handle h, int i, void* hip_stream);
-int nasr_apply_adam(nasr_handle h, float grad_scale); /* g*grad_scale, TF Adam, step += 1 (async) */
+int nasr_apply_adam(nasr_handle h, float grad_scale);
+/* Diagnostics - what ONE GPU can show of a collective that co-runs with the step (average_gradients moved under the
+ * backward pass, tfnetwork.py:72-86): waits on `hip_stream` for bucket i like nasr_grad_bucket_wait, then launches there a
+ * kernel shaped like a ring all-reduce step over that bucket - nblocks workgroups of 256 threads, each sweeping its slice
+ * `passes` times with 16-byte loads and stores, the data unchanged.  tools/rccl_standin.py, tests/test_gpu_persist.py. */
+int nasr_diag_bucket_traffic(nasr_handle h, int i, void* hip_stream, int nblocks, int passes); /* g*grad_scale, TF Adam, step += 1 (async) */
 /* copy the gradients out (TF order) / load externally reduced gradients (TF order) for nasr_apply_adam:
  * the single-process form of average_gradients (several towers time-sliced on one GPU). */
 int nasr_get_grads(nasr_handle h, float* flat, int64_t n);

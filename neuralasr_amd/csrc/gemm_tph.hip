@@ -351,14 +351,21 @@ void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT,
 }
 
 // ------------------------------------------------------------------ the GEMM
-template <int TMW>
-__global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
+// WM x WN waves, each with a (32 TMW) x 64 piece of the (32 TMW WM) x (64 WN) block tile.  <4,2,4> / <3,2,4>: the 256 (192) x
+// 256 tiles of the step, 8 waves, one block per CU.  <4,1,3>: a 128 x 192 tile on THREE waves and 80 KB of LDS - what fits on
+// a CU beside a workgroup of the persistent recurrence (lstm_persist.hip: 5 waves, two of them on one SIMD), for weight
+// gradients that run under the BPTT launch of the layer below (nasr_api.hip, weight_grads on the side stream).
+// DBG (diagnostics of the co-residency experiment, NASR_SIDE_DBG, side launches only): 1 = no operand DMA after the first
+// step, 2 = no MFMAs - results are garbage, timing only.
+template <int TMW, int WM, int WN, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void gemm_tph_kernel(GemmTPHParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-  constexpr int TM = 64 * TMW;
+  constexpr int TM = 32 * TMW * WM, TN = 64 * WN;
+  constexpr int NWV = WM * WN;               // waves
   constexpr int NA = TM / 32;                // A row blocks
-  constexpr int NRB = NA + 8;                // + B row blocks
+  constexpr int NRB = NA + 2 * WN;           // + B row blocks
   constexpr int NT = NRB * 2 * 2;            // tiles per step: 2 k-blocks x row blocks x 2 parts
-  constexpr int NW = (NT + 7) / 8;           // DMA instructions per wave and step (8 or 7)
+  constexpr int NW = (NT + NWV - 1) / NWV;   // DMA instructions per wave and step
   constexpr int BUFB = NT * HTB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -370,11 +377,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
     by = xr * p.sr + r; bx = xc * p.sc + c; bzz = xz * p.sz + z;
     if (by >= p.gy || bx >= p.gx || bzz >= p.gz) return;      // padding of an uneven sub-grid (block-uniform)
   }
-  const int m0 = by * TM, n0 = bx * 256;
+  const int m0 = by * TM, n0 = bx * TN;
   const int bz = p.nbatch > 1 ? (int)(bzz % p.nbatch) : 0, zs = p.nbatch > 1 ? (int)(bzz / p.nbatch) : bzz;
   const int kb0 = zs * p.kb_chunk;                       // even
   const int kb1 = min(p.kbs, kb0 + p.kb_chunk);
-  const int wm = w >> 2, wn = w & 3;
+  const int wm = w / WN, wn = w % WN;
 
   uint64_t zero = (uint64_t)g_tph_zero;
   asm volatile("" : "+s"(zero));
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
     const int buf = ((kb - kb0) >> 1) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kb + 2 < kb1) issue(kb + 2, buf ^ 1);   // (issued after the first fragment reads instead: 2 % slower)
+    if (kb + 2 < kb1 && !(DBG & 1)) issue(kb + 2, buf ^ 1);   // (issued after the first fragment reads instead: 2 % slower)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       f16x8 a[TMW][2], b[2][2];
@@ -442,7 +449,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
 #pragma unroll
       for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = chain3(acc[i][j], a[i], b[j]);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (DBG & 2) acc[i][j][0] += (float)a[i][0][0] * (float)b[j][1][0];
+          else acc[i][j] = chain3(acc[i][j], a[i], b[j]);
+        }
     }
   }
 
@@ -468,22 +478,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tph_kernel(GemmTPHParams p) {
     }
 }
 
+constexpr int TPH_LDS_SIDE = 2 * 40 * HTB;     // <4,1,3>: (4 + 6) row blocks x 2 k-blocks x 2 parts, two buffers
+
 hipError_t gemm_tph_prepare() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<4>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<4, 2, 4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TPH_LDS);
   if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<3, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             TPH_LDS);
+  for (const void* f : {reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3>), reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3, 1>),
+                        reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3, 2>), reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3, 3>)})
+    if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TPH_LDS_SIDE);
   return e;
 }
 
 // K split by a cost model in units of one k-step of one block: blocks run in rounds of 256 (one per CU), every slice keeps
 // >= 32 k-blocks, and each slab costs a write + a read of M x N floats at ~4 TB/s; slices are even numbers of k-blocks
-int gemm_tph_pick_split(int M, int N, int K, int nbatch) {
-  const int tm = gemm_tp_tile_rows(M);
-  const int tiles = ((M + tm - 1) / tm) * ((N + 255) / 256) * (nbatch > 1 ? 2 : 1);
+int gemm_tph_pick_split(int M, int N, int K, int nbatch, bool side) {
+  const int tm = side ? 128 : gemm_tp_tile_rows(M), tn = side ? 192 : 256;
+  const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn) * (nbatch > 1 ? 2 : 1);
   const int kbs = (K + 15) / 16;
-  const double kstep = 1.3e-6 * tm / 256.0;
+  const double kstep = side ? 0.9e-6 : 1.3e-6 * tm / 256.0;     // one step = two k-blocks of one block
   const double slab = (double)(nbatch > 1 ? 2 : 1) * M * N * 8.0 / 4e12 / kstep;
   int best = 1;
   double best_cost = 1e30;
@@ -508,12 +523,12 @@ void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st) {
   p.kb_chunk = per;
   p.split_k = (p.kbs + per - 1) / per;
   p.slabs = g.slabs;
-  const int tm = g.tile_rows ? g.tile_rows : gemm_tp_tile_rows(g.M);
+  const int tm = g.side ? 128 : g.tile_rows ? g.tile_rows : gemm_tp_tile_rows(g.M), tn = g.side ? 192 : 256;
   p.nbatch = g.nbatch > 1 ? 2 : 1;
   p.a_bstride = (long long)g.a_bstride; p.b_bstride = (long long)g.b_bstride; p.c_bstride = (long long)g.c_bstride;
   p.ainv_bstride = (long long)g.ainv_bstride; p.binv_bstride = (long long)g.binv_bstride;
   p.a_kb_shift1 = g.a_kshift1 / 16;
-  dim3 grid((g.N + 255) / 256, (g.M + tm - 1) / tm, p.split_k * p.nbatch);
+  dim3 grid((g.N + tn - 1) / tn, (g.M + tm - 1) / tm, p.split_k * p.nbatch);
   p.swz = 0;
   p.gx = (int)grid.x; p.gy = (int)grid.y; p.gz = (int)grid.z;
   p.pr = p.pc = p.pz = 1; p.sr = p.gy; p.sc = p.gx; p.sz = p.gz;
@@ -534,8 +549,13 @@ void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st) {
       }
     if (p.swz) grid = dim3(8 * p.sr * p.sc * p.sz, 1, 1);
   }
-  if (tm == 192) hipLaunchKernelGGL(gemm_tph_kernel<3>, grid, dim3(512), TPH_LDS, st, p);
-  else hipLaunchKernelGGL(gemm_tph_kernel<4>, grid, dim3(512), TPH_LDS, st, p);
+  static const int side_dbg = [] { const char* e = getenv("NASR_SIDE_DBG"); return e ? atoi(e) : 0; }();
+  if (g.side && side_dbg == 1) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3, 1>), grid, dim3(192), TPH_LDS_SIDE, st, p);
+  else if (g.side && side_dbg == 2) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3, 2>), grid, dim3(192), TPH_LDS_SIDE, st, p);
+  else if (g.side && side_dbg == 3) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3, 3>), grid, dim3(192), TPH_LDS_SIDE, st, p);
+  else if (g.side) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3>), grid, dim3(192), TPH_LDS_SIDE, st, p);
+  else if (tm == 192) hipLaunchKernelGGL((gemm_tph_kernel<3, 2, 4>), grid, dim3(512), TPH_LDS, st, p);
+  else hipLaunchKernelGGL((gemm_tph_kernel<4, 2, 4>), grid, dim3(512), TPH_LDS, st, p);
   if (p.split_k > 1) launch_reduce_slabs(g.slabs, p.split_k, (int64_t)p.nbatch * g.M * g.N, g.C, st);
 }
 

@@ -83,9 +83,10 @@ struct GemmTPHDesc {
   size_t a_bstride, b_bstride;
   int64_t c_bstride, ainv_bstride, binv_bstride;
   int a_kshift1;
+  bool side;                // the 3-wave 128 x 192 instantiation that fits beside a persistent-recurrence workgroup
 };
 hipError_t gemm_tph_prepare();
-int gemm_tph_pick_split(int M, int N, int K, int nbatch = 1);
+int gemm_tph_pick_split(int M, int N, int K, int nbatch = 1, bool side = false);
 void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st);
 
 // ---- LSTM recurrence (lstm.hip) ----
@@ -140,6 +141,7 @@ void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* 
 // rowpart [D*32][T*Bp], colpart [8/D][D*4Hp] (or NULL): partial maxima of |dG| per frame row / per gate column, written by the
 // kernel's memory wave; launch_tph_scales_from_parts turns them into operand scales (persist_dgmax_floats sizes both)
 size_t persist_dgmax_floats(int T, int Bp, int Hp, int D);
+void persist_set_bwd_lean(bool lean);            // BPTT launches declare 24 KB of LDS instead of 96 KB (process-wide)
 
 // ---- wide persistent forward recurrence (lstm_wide.hip): Hp = 2048, one launch per direction over all 256 CUs ----
 struct WideCtl {               // device words, zeroed before every launch
@@ -213,5 +215,7 @@ void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, AdamDe
 void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st);
 void launch_colsum_parts(const float* part, int nparts, int N, float* out, hipStream_t st);   // out[n] = sum_k part[k][n]
 void launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, hipStream_t st);
+// diagnostics: nblocks x 256 threads sweep buf[0..n) `passes` times with 16-byte loads / stores, data unchanged
+void launch_ring_standin(float* buf, int64_t n, int nblocks, int passes, hipStream_t st);
 
 }  // namespace nasr

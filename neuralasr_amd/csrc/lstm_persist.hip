@@ -47,6 +47,9 @@
 #ifndef NASR_BWD_EPOCH
 #define NASR_BWD_EPOCH 1   // BPTT hand-off: every partial sum carries an epoch bit in its last mantissa bit, consumers poll the sums
 #endif
+#ifndef NASR_BWD_NACC
+#define NASR_BWD_NACC 4    // accumulator chains per output group of the BPTT product (2 or 4)
+#endif
 #ifndef NASR_EP_DELAY
 #define NASR_EP_DELAY 0    // s_sleep units between "this CU has published" and the first load of the others' h
 #endif
@@ -250,6 +253,9 @@ struct PersistGeom {
 };
 
 constexpr int PERSIST_LDS_BYTES = 96 * 1024;   // > half of the CU's 160 KB: one workgroup per CU
+constexpr int PERSIST_LDS_LEAN = 24 * 1024;    // what the kernels use (LDS map below: 20.1 KB): leaves room for a 3-wave GEMM
+                                               // workgroup on the same CU (gemm_tph.hip <4,1,3>)
+static bool g_bwd_lean = false;                // persist_set_bwd_lean
 
 // LDS map (floats): red [2][4][4][64] | adg [2][256] | side [2][64][8] | xgb [2][64][4] | pfb [2][64][8] | info[8]
 constexpr int LDS_RED = 0, LDS_ADG = 2 * 4 * 4 * 64, LDS_SIDE = LDS_ADG + 2 * 256, LDS_XGB = LDS_SIDE + 2 * 64 * 8,
@@ -797,14 +803,19 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
       float av[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) av[v] = (64 * v + lane < 4 * NC) ? adg[par * 256 + 64 * v + lane] : 0.f;
-      f32x4 acc[NOG][2];
+      // NACC independent accumulator chains per output group: with NOG * NACC = 8 chains in flight the wave always has an
+      // MFMA ready to issue (it runs at priority 3: beside another kernel's MFMA waves it keeps the pipe for its phase)
+      constexpr int NACC = NASR_BWD_NACC;
+      f32x4 acc[NOG][NACC];
 #pragma unroll
-      for (int og = 0; og < NOG; ++og) { acc[og][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[og][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      for (int og = 0; og < NOG; ++og)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[og][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
       static_for<0, NC>([&](auto cc_) {
         constexpr int c = decltype(cc_)::value;
         static_for<0, NOG>([&](auto ogc) {
           constexpr int og = decltype(ogc)::value;
-          acc[og][c & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c / 16], wreg[og * NC + c], acc[og][c & 1], 4, c % 16, 0);
+          acc[og][c % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c / 16], wreg[og * NC + c], acc[og][c % NACC], 4, c % 16, 0);
         });
       });
       // 4. hand the partial rows to their consumers: unit k' -> consumer k'/NU, row element 4*(k'%NU) + utt
@@ -812,6 +823,7 @@ __global__ __launch_bounds__(320, 1) void lstm_persist_bwd_kernel(
 #pragma unroll
       for (int og = 0; og < NOG; ++og) {
         f32x4 sum = acc[og][0] + acc[og][1];
+        if constexpr (NACC == 4) sum = sum + (acc[og][2] + acc[og][3]);
         if constexpr (EP) {   // the last mantissa bit of every sum = the epoch of this use of the buffer
 #pragma unroll
           for (int i = 0; i < 4; ++i) sum[i] = __uint_as_float((__float_as_uint(sum[i]) & ~1u) | eb);
@@ -866,6 +878,10 @@ static PersistGeom make_geom(const LstmDims& dm, bool bwd) {
   g.fault = nullptr;
   return g;
 }
+
+// lean = true: the BPTT launches declare only the LDS they use, so that another kernel's workgroup can share their CUs.
+// Only for Hp = 512, where the kernel's 5 x 220 VGPRs alone keep it at one workgroup per CU.
+void persist_set_bwd_lean(bool lean) { g_bwd_lean = lean; }
 
 size_t persist_dgmax_floats(int T, int Bp, int Hp, int D) { return (size_t)D * 32 * T * Bp + (size_t)(8 / D) * D * 4 * Hp; }
 
@@ -933,8 +949,10 @@ void launch_lstm_persist_bwd(const LstmDims& dm, const float* Upb, const float* 
   // epoch-validated hand-off: the exchange buffer starts from epoch 0 (ctl_zeroed: the caller cleared it with *ctl)
   if (NASR_BWD_EPOCH && !ctl_zeroed) (void)hipMemsetAsync(xch, 0, persist_px_bytes(), st);
   dim3 grid(256), block(320);
+  // (lean only at Hp = 512, where the kernel's 5 x 220 VGPRs alone keep it at one workgroup per CU)
+  const int bwd_lds = (g_bwd_lean && dm.Hp == 512) ? PERSIST_LDS_LEAN : PERSIST_LDS_BYTES;
 #define NASR_PB(NUV)                                                                                                   \
-  hipLaunchKernelGGL((lstm_persist_bwd_kernel<NUV>), grid, block, PERSIST_LDS_BYTES, st, Upb, gates, dgbuf, cbuf, dout, \
+  hipLaunchKernelGGL((lstm_persist_bwd_kernel<NUV>), grid, block, bwd_lds, st, Upb, gates, dgbuf, cbuf, dout, \
                      seq_len, xch, ctl, sticky, gm, rowpart, colpart)
   switch (dm.Hp / 32) {
     case 2: NASR_PB(2); break;

@@ -152,6 +152,10 @@ struct nasr_ctx {
   unsigned* perr = nullptr;            // host-mapped sticky error word
   // in-library gradient exchange (nasr_comm_*): one RCCL rank per handle, collectives on a side stream
   void* comm = nullptr;                  // ncclComm_t
+  // nasr_comm_mean's own communicator (ncclCommSplit of `comm`, same ranks) and stream: the two host floats of a step do
+  // not queue up behind the step's gradient buckets.  NULL (old librccl): the mean shares `comm` and waits for them.
+  void* comm2 = nullptr;
+  hipStream_t comm_st2 = nullptr;
   int comm_rank = 0, comm_n = 1;
   hipStream_t comm_st = nullptr;
   hipEvent_t ev_comm = nullptr;
@@ -242,6 +246,17 @@ struct nasr_ctx {
   int32_t *seq_p = nullptr, *lablen_p = nullptr, *labels_p = nullptr, *cstart_p = nullptr, *cpos_p = nullptr,
           *rowmap_p = nullptr;
 
+  // Weight gradients under the BPTT of the layer below (persistent mode, Hp = 512, L > 1; NASR_WGRAD_OVERLAP=0 turns it off): weight_grads(l)
+  // runs on a low-priority side stream in the 3-wave GEMM instantiation that fits on a CU beside a persistent workgroup,
+  // from its own copies of everything the main stream rewrites meanwhile (dG^T planes, column scales, partial column sums,
+  // slabs: index l & 1), and is joined before layer l's gradients are released / Adam.
+  bool wg_overlap = false;
+  hipStream_t wst = nullptr;
+  hipEvent_t ev_dx = nullptr;
+  std::vector<hipEvent_t> ev_wg;             // per layer: its weight gradients are complete
+  std::vector<char> wg_pending;              // ... and the main stream has not waited for that yet
+  DevBuf GTTP2, csws2, slabs2;
+  SV sc_gc2;
   DevBuf XTP, X0TTP, GTP, GTTP;   // tiled-plane copies of activations / dG
   std::vector<DevBuf> OTT;        // per layer: planes of out[l] with the frame index as contraction index (weight gradients)
   std::vector<char> ott_valid;    // ... written by the forward pass of this step already (together with the planes of layer l+1's input)
@@ -721,6 +736,10 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
     for (int l = 0; l < h->L; ++l) ok &= h->OTT[l].ensure(tph_bytes(D * Hp, (int)R), &grew);
     ok &= h->GTP.ensure(tph_bytes((int)R, wmax), &grew);
     ok &= h->GTTP.ensure(tph_bytes(wmax, (int)R), &grew);
+    if (h->wg_overlap) {
+      ok &= h->GTTP2.ensure(tph_bytes(wmax, (int)R), &grew);
+      ok &= h->sc_gc2.ensure((size_t)wmax);
+    }
     if (h->ndense) ok &= h->DTP.ensure(tph_bytes(ipmax, (int)R), &grew);
     {
       const size_t n15 = std::max<size_t>(R, (size_t)std::max(ipmax, wmax));
@@ -753,6 +772,7 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   for (int i = 0; i < h->ndense; ++i) csw = std::max(csw, h->dWp[i]);
   // column-sum partials: 32 rows of launch_colsum, or the 64-row partials of the split pass (tp_split2_parts)
   ok &= h->csws.ensure((size_t)std::max(32, tp_split2_parts((int)R)) * csw * 4, &grew);
+  if (h->wg_overlap) ok &= h->csws2.ensure((size_t)std::max(32, tp_split2_parts((int)R)) * csw * 4, &grew);
   ok &= h->amax.ensure((size_t)Tp * Bp * 4, &grew);
   ok &= h->ids.ensure((size_t)B * Tp * 4, &grew);
   ok &= h->lens.ensure((size_t)Bp * 4, &grew);
@@ -1016,6 +1036,12 @@ int stage(nasr_ctx* h, const float* feats, const int32_t* seq_len, const int32_t
 
 inline float* dout_of(nasr_ctx* h, int) { return h->dout.as<float>(); }
 inline float* dg_of(nasr_ctx* h, int) { return h->dgbuf.as<float>(); }
+// what weight_grads(l) reads of layer l's dG: with the overlap on, odd layers have copies of their own (the main stream
+// is rewriting the others for layer l-1 while the side stream still reads these)
+inline bool wg_alt(const nasr_ctx* h, int l) { return h->wg_overlap && (l & 1); }
+inline unsigned char* gttp_of(nasr_ctx* h, int l) { return (wg_alt(h, l) ? h->GTTP2 : h->GTTP).as<unsigned char>(); }
+inline float* csws_of(nasr_ctx* h, int l) { return (wg_alt(h, l) ? h->csws2 : h->csws).as<float>(); }
+inline nasr_ctx::SV& gc_of(nasr_ctx* h, int l) { return wg_alt(h, l) ? h->sc_gc2 : h->sc_gc; }
 
 // ---- the per-timestep loops over steps [s0, s1), optionally replayed from a hipGraph -----------
 int run_steps(nasr_ctx* h, int l, bool bwd, int s0, int s1, hipStream_t st) {
@@ -1124,9 +1150,9 @@ void dg_scales(nasr_ctx* h, int l, int R, bool rows, hipStream_t st) {
   if (h->dgmax_layer == l) {
     const float* rp = h->dgmax.as<float>();
     launch_tph_scales_from_parts(rp, h->D * 32, R, rows ? h->sc_gr.sp() : nullptr, rows ? h->sc_gr.ip() : nullptr,
-                                 rp + (size_t)h->D * 32 * R, 8 / h->D, DN, h->sc_gc.sp(), h->sc_gc.ip(), st);
+                                 rp + (size_t)h->D * 32 * R, 8 / h->D, DN, gc_of(h, l).sp(), gc_of(h, l).ip(), st);
   } else {
-    pl_scales(h, dg_of(h, l), R, DN, DN, rows ? &h->sc_gr : nullptr, &h->sc_gc, st);
+    pl_scales(h, dg_of(h, l), R, DN, DN, rows ? &h->sc_gr : nullptr, &gc_of(h, l), st);
   }
 }
 
@@ -1161,8 +1187,7 @@ void gemm_dx(nasr_ctx* h, int l, int R, hipStream_t st) {
   const float* A = dg_of(h, l);
   float* C = l > 0 ? dout_of(h, l - 1) : h->dYbuf[h->npre - 1].as<float>();
   dg_scales(h, l, R, true, st);
-  pl_split(A, h->GTP.as<unsigned char>(), h->GTTP.as<unsigned char>(), R, D * N4, D * N4, h->sc_gr.sp(), h->sc_gc.sp(),
-           h->csws.as<float>(), st);
+  pl_split(A, h->GTP.as<unsigned char>(), gttp_of(h, l), R, D * N4, D * N4, h->sc_gr.sp(), gc_of(h, l).sp(), csws_of(h, l), st);
   h->gttp_layer = l;   // weight_grads(l): transposed planes and column-sum partials of dG are there
   GemmTPHDesc g{};
   g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
@@ -1323,19 +1348,31 @@ int ctc_forward(nasr_ctx* h) {
   return NASR_OK;
 }
 
-// weight / bias gradients of layer l from its complete dG (on the main stream)
-int weight_grads(nasr_ctx* h, int l) {
+// weight / bias gradients of layer l from its complete dG, on stream ws: the main stream, or (side = true) the side stream
+// with the 3-wave GEMM instantiation that shares the CUs with the persistent BPTT launch of the layer below
+int weight_grads(nasr_ctx* h, int l, hipStream_t ws, bool side) {
   const int Bp = h->Bp, T = h->T, D = h->D, Hp = h->Hp, N4 = h->N4;
   const int R = T * Bp;
   float* dG = dg_of(h, l);
-  hipStream_t ws = h->st;
-  // tiled-plane copies with the frame index as contraction index (K = R)
-  unsigned char* GT = h->GTTP.as<unsigned char>();
+  unsigned char* GT = gttp_of(h, l);
+  float* cs_part = csws_of(h, l);
+  nasr_ctx::SV& gc = gc_of(h, l);
+  DevBuf& slab_buf = side ? h->slabs2 : h->slabs;
+  auto slabs_for = [&](int split, int M, int N) -> float* {
+    if (split <= 1) return nullptr;
+    bool grew = false;
+    return slab_buf.ensure((size_t)split * M * N * 4, &grew) ? slab_buf.as<float>() : nullptr;
+  };
   const int nkb = (R + 15) / 16;
+  // The side instantiation splits K exactly as the main one would: every output element then sums the same k-blocks in
+  // the same order whatever the tile shape - the gradients are bitwise those of the serial order.  (NASR_SIDE_SPLIT=own:
+  // the split its own cost model picks, for the A/B logs.)
+  static const bool own_split = [] { const char* e = getenv("NASR_SIDE_SPLIT"); return e && e[0] == 'o'; }();
+  const bool side_split = side && own_split;
   // one pass over dG: its transposed planes + 64-row partial column sums (already there when gemm_dx(l) ran)
   if (h->gttp_layer != l) {
     dg_scales(h, l, R, false, ws);
-    pl_split(dG, nullptr, GT, R, D * N4, D * N4, nullptr, h->sc_gc.sp(), h->csws.as<float>(), ws);
+    pl_split(dG, nullptr, GT, R, D * N4, D * N4, nullptr, gc.sp(), cs_part, ws);
   }
   h->gttp_layer = -1;
   const ActScale ao = act_out(h), ai = lstm_in_scale(h, l);
@@ -1351,12 +1388,13 @@ int weight_grads(nasr_ctx* h, int l) {
     g.A = l == 0 ? h->X0TTP.as<unsigned char>() : h->OTT[l - 1].as<unsigned char>();
     g.B = GT; g.C = h->G + h->off_wx[l];
     g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
-    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K);
-    g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
+    g.side = side;
+    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K, 1, side_split);
+    g.slabs = slabs_for(g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-    pl_gemm(g, ai.cinv, h->sc_gc.ip(), ws);
+    pl_gemm(g, ai.cinv, gc.ip(), ws);
   }
-  launch_colsum_parts(h->csws.as<float>(), tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
+  launch_colsum_parts(cs_part, tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
   {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw); both directions in one launch
     GemmTPHDesc g{};
     g.A = h->OTT[l].as<unsigned char>(); g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
@@ -1366,12 +1404,22 @@ int weight_grads(nasr_ctx* h, int l) {
     g.a_bstride = (size_t)(Hp / 32) * pl_rb_bytes(nkb); g.b_bstride = (size_t)(N4 / 32) * pl_rb_bytes(nkb);
     g.c_bstride = (int64_t)Hp * N4;            // off_u[l*D + 1] - off_u[l*D] (build_layout)
     g.a_kshift1 = Bp;
-    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K, D);
-    g.slabs = ensure_slabs(h, g.split_k * D, g.M, g.N);
+    g.side = side;
+    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K, D, side_split);
+    g.slabs = slabs_for(g.split_k * D, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
-    pl_gemm(g, ao.cinv, h->sc_gc.ip(), ws, Hp, N4);
+    pl_gemm(g, ao.cinv, gc.ip(), ws, Hp, N4);
   }
   HIPCHK(h, hipGetLastError());
+  return NASR_OK;
+}
+
+// the main stream waits for layer l's side-stream weight gradients (no-op when there are none outstanding)
+int wg_join(nasr_ctx* h, int l) {
+  if (l >= 0 && l < h->L && h->wg_pending[l]) {
+    HIPCHK(h, hipStreamWaitEvent(h->st, h->ev_wg[l], 0));
+    h->wg_pending[l] = 0;
+  }
   return NASR_OK;
 }
 
@@ -1432,15 +1480,33 @@ int backward(nasr_ctx* h) {
       if (rc) return rc;
       h->n_bwd_launch += h->persist ? 1 : (h->wide && wide_supported(h->Hp, h->Bp)) ? D : T;
     }
-    if (defer && l + 1 < h->L && h->bucket_of_layer[l + 1] >= 0)   // the layer above's bucket, held back over this launch
+    if (defer && l + 1 < h->L && h->bucket_of_layer[l + 1] >= 0) {   // the layer above's bucket, held back over this launch
+      if (int rc = wg_join(h, l + 1)) return rc;
       HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l + 1]], h->st));
+    }
     PhaseScope ps(h, PH_WGRAD);
     if (l > 0 || h->npre > 0) gemm_dx(h, l, R, h->st);   // critical path first
-    int rc = weight_grads(h, l);
-    if (rc) return rc;
-    if (h->bucket_of_layer[l] >= 0 && !(defer && l > 0))
+    // layer l's weight gradients feed nothing before Adam: with the overlap on they leave the main stream here and run
+    // beside the persistent BPTT launch of layer l-1 (tfnetwork.py:120-128: the gradients are a set, nothing orders them)
+    const bool side = h->wg_overlap && h->persist && l > 0 && h->gttp_layer == l;
+    if (side) {
+      HIPCHK(h, hipEventRecord(h->ev_dx, h->st));
+      HIPCHK(h, hipStreamWaitEvent(h->wst, h->ev_dx, 0));
+      int rc = weight_grads(h, l, h->wst, true);
+      if (rc) return rc;
+      HIPCHK(h, hipEventRecord(h->ev_wg[l], h->wst));
+      h->wg_pending[l] = 1;
+    } else {
+      int rc = weight_grads(h, l, h->st, false);
+      if (rc) return rc;
+    }
+    if (h->bucket_of_layer[l] >= 0 && !(defer && l > 0)) {
+      if (int rc = wg_join(h, l)) return rc;
       HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l]], h->st));
+    }
   }
+  for (int l = 0; l < h->L; ++l)
+    if (int rc = wg_join(h, l)) return rc;     // whatever is still out: before the last bucket / Adam
   for (int i = h->npre - 1; i >= 0; --i) {
     PhaseScope ps(h, PH_WGRAD);
     int rc = dense_backward(h, i, i == 0 ? h->X0.as<float>() : h->Ybuf[i - 1].as<float>(),
@@ -1692,6 +1758,22 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   h->Ybuf.resize(h->ndense);
   h->dYbuf.resize(h->ndense);
   if (hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking) != hipSuccess) return bail(NASR_ERR_HIP, "hipStreamCreate (copy stream) failed");
+  {
+    const char* eo = getenv("NASR_WGRAD_OVERLAP");
+    h->wg_overlap = !(eo && eo[0] == '0') && h->persist && h->Hp == 512 && h->L > 1;   // on unless NASR_WGRAD_OVERLAP=0
+    h->ev_wg.assign(h->L, nullptr);
+    h->wg_pending.assign(h->L, 0);
+    if (h->wg_overlap) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = lowest priority (largest number)
+      if (hipStreamCreateWithPriority(&h->wst, hipStreamNonBlocking, lo) != hipSuccess ||
+          hipEventCreateWithFlags(&h->ev_dx, hipEventDisableTiming) != hipSuccess)
+        return bail(NASR_ERR_HIP, "set-up of the weight-gradient side stream failed");
+      for (auto& e : h->ev_wg)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(NASR_ERR_HIP, "hipEventCreate failed");
+      persist_set_bwd_lean(true);
+    }
+  }
   for (BatchSlot& bs : h->slots)
     if (hipEventCreateWithFlags(&bs.ev_copy, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&bs.ev_released, hipEventDisableTiming) != hipSuccess)
@@ -1754,7 +1836,11 @@ int nasr_destroy(nasr_handle h) {
   if (h->wpart) (void)hipFree(h->wpart);
   if (h->wctl) (void)hipFree(h->wctl);
   if (h->perr) (void)hipHostFree(h->perr);
-  for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->GTP, &h->GTTP, &h->scws}) b->release();
+  for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->GTP, &h->GTTP, &h->scws, &h->GTTP2, &h->csws2, &h->slabs2}) b->release();
+  h->sc_gc2.release();
+  if (h->wst) { (void)hipStreamSynchronize(h->wst); (void)hipStreamDestroy(h->wst); }
+  if (h->ev_dx) (void)hipEventDestroy(h->ev_dx);
+  for (hipEvent_t e : h->ev_wg) if (e) (void)hipEventDestroy(e);
   for (auto& b : h->OTT) b.release();
   for (nasr_ctx::SV* v : {&h->sc15, &h->sc_x0r, &h->sc_x0c, &h->sc_gr, &h->sc_gc}) v->release();
   for (auto* vec : {&h->sc_yr, &h->sc_yc, &h->sc_wr, &h->sc_wc, &h->sc_dr, &h->sc_dc})
@@ -1963,6 +2049,17 @@ int nasr_grad_bucket_wait(nasr_handle h, int i, void* hip_stream) {
   if (!h) return NASR_ERR_ARG;
   if (i < 0 || i >= (int)h->buckets.size()) return h->fail(NASR_ERR_ARG, "nasr_grad_bucket_wait: bad index");
   HIPCHK(h, hipStreamWaitEvent((hipStream_t)hip_stream, h->ev_bucket[i], 0));
+  return NASR_OK;
+}
+
+int nasr_diag_bucket_traffic(nasr_handle h, int i, void* hip_stream, int nblocks, int passes) {
+  if (!h) return NASR_ERR_ARG;
+  if (i < 0 || i >= (int)h->buckets.size() || nblocks < 1 || nblocks > 1024 || passes < 1)
+    return h->fail(NASR_ERR_ARG, "nasr_diag_bucket_traffic: bad bucket index, nblocks (1..1024) or passes");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamWaitEvent((hipStream_t)hip_stream, h->ev_bucket[i], 0));
+  launch_ring_standin(h->Gbase + h->buckets[i].first, h->buckets[i].second, nblocks, passes, (hipStream_t)hip_stream);
+  HIPCHK(h, hipGetLastError());
   return NASR_OK;
 }
 
@@ -2292,6 +2389,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, Uid, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommSplit)(void*, int, int, void**, void*) = nullptr;     // optional (RCCL >= 2.18): a second communicator of the same ranks
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
   std::string why;
@@ -2315,6 +2413,7 @@ RcclApi& rccl() {
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(lib, "ncclAllReduce"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  api.CommSplit = reinterpret_cast<decltype(api.CommSplit)>(dlsym(lib, "ncclCommSplit"));
   api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce;
   if (!api.ok) api.why = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
   return api;
@@ -2363,6 +2462,13 @@ int nasr_comm_init(nasr_handle h, const void* id128, int rank, int nranks) {
   HIPCHK(h, hipStreamCreateWithFlags(&h->comm_st, hipStreamNonBlocking));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
   HIPCHK(h, hipMalloc(&h->comm_scratch, 64 * sizeof(float)));
+  if (r.CommSplit) {                      // collective over all ranks of `comm`: every rank gets here (same library everywhere)
+    void* c2 = nullptr;
+    if (r.CommSplit(c, 0, rank, &c2, nullptr) == 0 && c2) {
+      h->comm2 = c2;
+      HIPCHK(h, hipStreamCreateWithFlags(&h->comm_st2, hipStreamNonBlocking));
+    }
+  }
   return NASR_OK;
 }
 
@@ -2393,11 +2499,16 @@ int nasr_comm_mean(nasr_handle h, float* vals, int n) {
   if (!h->comm) return NASR_OK;                   // one rank: the mean is the value
   RcclApi& r = rccl();
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->comm_scratch, vals, (size_t)n * 4, hipMemcpyHostToDevice, h->st));
-  const int rc = r.AllReduce(h->comm_scratch, h->comm_scratch, (size_t)n, kNcclFloat, kNcclSum, h->comm, h->st);
+  // On its own communicator and stream when the library offers ncclCommSplit: the collective of a few floats neither waits
+  // for the gradient buckets of the step in flight nor for the compute stream.  Otherwise (one communicator executes its
+  // collectives in issue order) it goes behind them on the compute stream, as documented in include/nasr.h.
+  void* c = h->comm2 ? h->comm2 : h->comm;
+  hipStream_t st = h->comm2 ? h->comm_st2 : h->st;
+  HIPCHK(h, hipMemcpyAsync(h->comm_scratch, vals, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  const int rc = r.AllReduce(h->comm_scratch, h->comm_scratch, (size_t)n, kNcclFloat, kNcclSum, c, st);
   if (rc) return rccl_fail(h, "ncclAllReduce", rc);
-  HIPCHK(h, hipMemcpyAsync(vals, h->comm_scratch, (size_t)n * 4, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
+  HIPCHK(h, hipMemcpyAsync(vals, h->comm_scratch, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) vals[i] /= (float)h->comm_n;
   return NASR_OK;
 }
@@ -2407,6 +2518,11 @@ int nasr_comm_destroy(nasr_handle h) {
   if (!h->comm) return NASR_OK;
   (void)hipSetDevice(h->device);
   if (h->comm_st) (void)hipStreamSynchronize(h->comm_st);
+  if (h->comm_st2) (void)hipStreamSynchronize(h->comm_st2);
+  if (h->comm2) (void)rccl().CommDestroy(h->comm2);
+  h->comm2 = nullptr;
+  if (h->comm_st2) (void)hipStreamDestroy(h->comm_st2);
+  h->comm_st2 = nullptr;
   (void)rccl().CommDestroy(h->comm);
   h->comm = nullptr;
   if (h->comm_st) (void)hipStreamDestroy(h->comm_st);

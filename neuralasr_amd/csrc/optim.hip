@@ -132,4 +132,25 @@ void launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, hipSt
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, S, n, out);
 }
 
+// ---- diagnostics: a kernel shaped like a ring all-reduce step ---------------------------------------------------------
+// `nblocks` workgroups of 256 threads; each sweeps its slice of the buffer `passes` times with 16-byte loads and stores
+// (x * 1: the data keep their bits), i.e. it holds its CUs for as long as RCCL's ring kernels hold theirs and moves bytes
+// the way they do - what a single GPU can show of a collective that co-runs with the step (nasr_diag_bucket_traffic).
+__global__ __launch_bounds__(256) void ring_standin_kernel(float4* __restrict__ buf, long long n4, int passes) {
+  const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+  for (int p = 0; p < passes; ++p)
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+      float4 v = buf[i];
+      v.x *= 1.f; v.y *= 1.f; v.z *= 1.f; v.w *= 1.f;
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));    // keep the multiply and the store
+      buf[i] = v;
+    }
+}
+
+void launch_ring_standin(float* buf, int64_t n, int nblocks, int passes, hipStream_t st) {
+  // buckets start at multiples of 32 floats from a 256-byte aligned allocation: 16-byte accesses are aligned
+  hipLaunchKernelGGL(ring_standin_kernel, dim3(nblocks), dim3(256), 0, st, reinterpret_cast<float4*>(buf), (long long)(n / 4), passes);
+}
+
 }  // namespace nasr

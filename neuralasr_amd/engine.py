@@ -326,6 +326,11 @@ class Engine:
         self._ck(self.lib.nasr_settle_step(self.h, int(bool(previous)), byref(v)))
         return bool(v.value)
 
+    def diag_bucket_traffic(self, i, stream, nblocks, passes):
+        """Diagnostics: a ring-all-reduce-shaped kernel over bucket i on `stream`, behind the bucket's event (include/nasr.h)."""
+        from ctypes import c_void_p
+        self._ck(self.lib.nasr_diag_bucket_traffic(self.h, int(i), c_void_p(int(stream)), int(nblocks), int(passes)))
+
     def step_token(self):
         """Sequence number of the optimiser step apply_adam() enqueued last (include/nasr.h, nasr_step_token)."""
         return int(self.lib.nasr_step_token(self.h))

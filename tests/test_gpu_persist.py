@@ -16,10 +16,10 @@ pytestmark = [pytest.mark.gpu,
                                  reason='NASR_PERSIST=0 forces the per-step kernels: nothing persistent to test')]
 
 
-def make_engine(spec, lr=1e-3):
+def make_engine(spec, lr=1e-3, stream=None):
     from neuralasr_amd.engine import Engine
     return Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes,
-                  forget_bias=spec.forget_bias, learning_rate=lr)
+                  forget_bias=spec.forget_bias, learning_rate=lr, stream=stream)
 
 
 def rand_params(spec, seed):
@@ -251,3 +251,44 @@ def test_fp16_plane_and_fp32_forward_recurrence_agree(monkeypatch):
         spec, [np.asarray(p, np.float32).astype(np.float64) for p in params], feats, seq_len, labels, label_len)
     np.testing.assert_allclose(out['f16'][0], logits_o, atol=1e-4)
     assert out['f16'][1] == pytest.approx(loss_o, rel=2e-5)
+
+
+
+def test_no_abort_beside_a_cu_resident_collective_stand_in():
+    """A kernel shaped like a ring all-reduce step (64 workgroups that hold their CUs while they sweep a 21 MB gradient
+    bucket several times: nasr_diag_bucket_traffic) is released by the bucket events on a side stream in every step, with
+    the events held back over the next persistent BPTT launch (the default).  50 steps: no persistent launch may give up -
+    a collective beside the persistent kernels costs time, never the step - and the parameters stay those of an
+    undisturbed engine, bit for bit (the stand-in leaves the gradients as they are)."""
+    import torch
+    spec = O.ModelSpec(546, 500, 3, True, 'concat', 29)
+    B, T = 16, 120
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=3, var_len=True, Lmin=5, Lmax=20)
+    p0 = O.flatten(O.init_params(spec, seed=1)).astype(np.float32)
+    ts = torch.cuda.Stream()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        e = make_engine(spec, lr=1e-4, stream=ts.cuda_stream)
+        ref = make_engine(spec, lr=1e-4, stream=ts.cuda_stream)
+        for x in (e, ref):
+            x.set_params(p0)
+            assert x.recurrence_mode == 'persistent'
+        e.set_bucket_defer(True)
+        nb = len(e.grad_buckets())
+        assert nb == 3
+        for step in range(50):
+            e.upload_batch(feats, seq_len, labels, label_len)
+            e.compute_grads()
+            for i in range(nb):
+                e.diag_bucket_traffic(i, side.cuda_stream, 64, 6)
+            ts.wait_stream(side)
+            e.apply_adam(1.0)
+            if step < 3:
+                ref.train_step(feats, seq_len, labels, label_len)
+            if step == 2:
+                np.testing.assert_array_equal(e.get_params(), ref.get_params())
+        torch.cuda.synchronize()
+        assert not e.step_void()
+        assert e.persist_stats() == (0, 0) and e.recurrence_mode == 'persistent'
+        e.close()
+        ref.close()
