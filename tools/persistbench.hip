@@ -122,19 +122,19 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 8; ++i) printf(" %u", hc.xcc_count[i]);
     printf("\n");
     if (hc.pad[0] | hc.pad[1]) {
-      printf("   wave 0 cycles/step: loop-top %.0f  poll %.0f  payload %.0f  mfma %.0f  barrier %.0f  cell %.0f  store-ack %.0f\n", hc.pad[0] / (double)T,
+      printf("   wave 0 cycles/step: loop-top %.0f  round-barrier %.0f  h load+check %.0f  mfma %.0f  barrier %.0f  cell %.0f  publish %.0f\n", hc.pad[0] / (double)T,
              hc.pad[1] / (double)T, hc.pad[2] / (double)T, hc.pad[3] / (double)T, hc.pad[4] / (double)T, hc.pad[5] / (double)T, hc.pad[6] / (double)T);
       printf("   barrier arrival after wave 0 (cycles): w1 %.0f  w2 %.0f  w3 %.0f  mem %.0f   extra hand-off attempts of wave 0 per step %.3f\n", (int)hc.pad[7] / (double)T, (int)hc.pad[8] / (double)T,
              (int)hc.pad[9] / (double)T, (int)hc.pad[10] / (double)T, hc.pad[11] / (double)T);
     }
 #if defined(NASR_PSTAMP) && NASR_PSTAMP
     {   // every workgroup's wave 0: the slowest chain sets the step; a phase that waits for others (poll) is shortest there
-      const char* nm[7] = {"loop-top", "poll", "payload", "mfma", "barrier", "cell", "store-ack"};
+      const char* nm[7] = {"loop-top", "round-barrier", "h-load+check", "mfma", "barrier", "cell", "publish"};
       for (int ph = 0; ph < 7; ++ph) {
         std::vector<double> v;
         for (int i = 0; i < 256; ++i) v.push_back(hc.stamps[i][ph] / (double)T);
         std::sort(v.begin(), v.end());
-        printf("   fwd %-9s over 256 CUs: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f\n", nm[ph], v[0], v[25], v[128], v[230], v[255]);
+        printf("   fwd %-15s over 256 CUs: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f\n", nm[ph], v[0], v[25], v[128], v[230], v[255]);
       }
       int lo = 0;
       for (int i = 1; i < 256; ++i) if (hc.stamps[i][1] < hc.stamps[lo][1]) lo = i;
@@ -161,18 +161,18 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(&hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
     printf("backward: per-step %.3f us/step   persistent %.3f us/step (%.3f ms)   error word %u\n", bstep * 1000 / T, ms * 1000 / T, ms, hc.error);
     if (hc.pad[0] | hc.pad[1]) {
-      printf("   wave 0 cycles/step: tail+prefetch %.0f  poll %.0f  partial loads+sum %.0f  cell bwd %.0f  barrier %.0f  mfma+stores %.0f  store-ack %.0f   extra hand-off attempts per step %.3f\n",
+      printf("   wave 0 cycles/step: tail+prefetch %.0f  round-barrier %.0f  partial loads+check+sum %.0f  cell bwd %.0f  barrier %.0f  mfma+stores %.0f  publish %.0f   extra hand-off attempts per step %.3f\n",
              hc.pad[0] / (double)T, hc.pad[1] / (double)T, hc.pad[2] / (double)T, hc.pad[3] / (double)T, hc.pad[4] / (double)T, hc.pad[5] / (double)T,
              hc.pad[6] / (double)T, hc.pad[11] / (double)T);
     }
 #if defined(NASR_PSTAMP) && NASR_PSTAMP
     {
-      const char* nm[7] = {"tail", "poll", "loads+sum", "cell", "barrier", "mfma+st", "store-ack"};
+      const char* nm[7] = {"tail", "round-barrier", "loads+check+sum", "cell", "barrier", "mfma+st", "publish"};
       for (int ph = 0; ph < 7; ++ph) {
         std::vector<double> v;
         for (int i = 0; i < 256; ++i) v.push_back(hc.stamps[i][ph] / (double)T);
         std::sort(v.begin(), v.end());
-        printf("   bwd %-9s over 256 CUs: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f\n", nm[ph], v[0], v[25], v[128], v[230], v[255]);
+        printf("   bwd %-15s over 256 CUs: min %.0f  p10 %.0f  median %.0f  p90 %.0f  max %.0f\n", nm[ph], v[0], v[25], v[128], v[230], v[255]);
       }
       int lo = 0;
       for (int i = 1; i < 256; ++i) if (hc.stamps[i][1] < hc.stamps[lo][1]) lo = i;
