@@ -686,6 +686,23 @@ def main():
                 except Exception as exc:      # noqa: BLE001 - a secondary workload never takes the line down
                     sec[name] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
             out['secondary'] = sec
+        # What TensorFlowNetwork.train also runs in every step (tfnetwork.py:61-70,188-189): the width-100 beam search + LER on the
+        # step's logits.  Host code here (nasr_ctc_beam_search, one thread per utterance) and NOT part of `value`: HipNetwork.train
+        # reports the greedy LER by default because this costs many steps' worth of time on the GPU box's cores.
+        if world == 1 and not args.no_secondary:
+            try:
+                lg = eng.forward(feats, seq_len)
+                t_b = time.perf_counter()
+                eng.beam_search(lg, seq_len, 100)
+                out['beam_ms_per_step'] = {'value': (time.perf_counter() - t_b) * 1e3, 'beam_width': 100, 'logit_frames': int(lg.shape[0]),
+                                           'utterances': B, 'host_threads': min(B, os.cpu_count() or 1),
+                                           'vs_step': (time.perf_counter() - t_b) * 1e3 / ms,
+                                           'note': 'tf.nn.ctc_beam_search_decoder defaults on the logits of the timed weights (random init + '
+                                                   'the timed Adam steps: near-flat posteriors, the decoder\'s slow case); see '
+                                                   'tools/beamtime.py for trained-looking posteriors'}
+                eng.upload_batch(feats, seq_len, labels, label_len)
+            except Exception as exc:      # noqa: BLE001
+                out['beam_ms_per_step'] = {'error': f'{type(exc).__name__}: {exc}'[:200]}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, B, 1234)
         else:

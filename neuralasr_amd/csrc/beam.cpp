@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <deque>
 #include <limits>
 #include <memory>
 #include <thread>
@@ -31,41 +32,63 @@ struct Prob {
   void reset() { total = blank = label = kLogZero; }
 };
 
+// One prefix of the beam tree.  Children sit in a flat array indexed by label, allocated from the decoder's arena on the
+// first extension (a hash map per entry and a heap allocation per child made the decoder 5-10x slower than this).
 struct Entry {
   Entry* parent = nullptr;
   int label = -1;
   Prob oldp, newp;
-  std::unordered_map<int, std::unique_ptr<Entry>> children;
+  Entry** kids = nullptr;
   bool active() const { return newp.total != kLogZero; }
-  Entry* child(int lab) {
-    auto it = children.find(lab);
-    if (it != children.end()) return it->second.get();
-    auto e = std::make_unique<Entry>();
-    e->parent = this;
-    e->label = lab;
-    Entry* raw = e.get();
-    children.emplace(lab, std::move(e));
-    return raw;
+};
+
+struct Arena {
+  int C;
+  std::deque<Entry> entries;
+  std::deque<std::vector<Entry*>> kid_arrays;
+  explicit Arena(int c) : C(c) {}
+  Entry* child(Entry* p, int lab) {
+    if (!p->kids) {
+      kid_arrays.emplace_back((size_t)C, nullptr);
+      p->kids = kid_arrays.back().data();
+    }
+    Entry*& slot = p->kids[lab];
+    if (!slot) {
+      entries.emplace_back();
+      slot = &entries.back();
+      slot->parent = p;
+      slot->label = lab;
+    }
+    return slot;
   }
 };
 
-// bounded "top N by newp.total" container
+// bounded "top N by newp.total" container: a min-heap on the total, so the bottom is the front and a push that evicts it
+// costs O(log N) (the entries' totals do not change while they sit in it)
 struct Leaves {
   size_t cap;
   std::vector<Entry*> v;
   explicit Leaves(size_t c) : cap(c) {}
   static bool better(const Entry* a, const Entry* b) { return a->newp.total > b->newp.total; }
-  Entry* bottom() const { return *std::min_element(v.begin(), v.end(), [](const Entry* a, const Entry* b) { return a->newp.total < b->newp.total; }); }
+  Entry* bottom() const { return v.front(); }
   void push(Entry* e) {
-    if (v.size() < cap) { v.push_back(e); return; }
-    auto it = std::min_element(v.begin(), v.end(), [](const Entry* a, const Entry* b) { return a->newp.total < b->newp.total; });
-    if (e->newp.total > (*it)->newp.total) *it = e;
+    if (v.size() < cap) {
+      v.push_back(e);
+      std::push_heap(v.begin(), v.end(), better);
+      return;
+    }
+    if (e->newp.total > v.front()->newp.total) {
+      std::pop_heap(v.begin(), v.end(), better);
+      v.back() = e;
+      std::push_heap(v.begin(), v.end(), better);
+    }
   }
 };
 
 void decode_one(const float* logits, size_t frame_stride, int T, int C, int beam_width, bool merge_repeated,
                 int32_t* ids_out, int32_t* len_out, float* logp_out) {
   const int blank = C - 1;
+  Arena arena(C);
   Entry root;
   root.newp.total = 0.f;
   root.newp.blank = 0.f;
@@ -104,19 +127,25 @@ void decode_one(const float* logits, size_t frame_stride, int T, int C, int beam
       if (!candidate(b->oldp)) continue;
       for (int lab = 0; lab < C; ++lab) {
         if (lab == blank) continue;
-        Entry* c = b->child(lab);
-        if (c->active()) continue;
-        c->newp.blank = kLogZero;
-        const float prev = (c->label == b->label) ? b->oldp.blank : b->oldp.total;
-        c->newp.label = lp[lab] + prev;
-        c->newp.total = c->newp.label;
-        if (candidate(c->newp)) {
-          if (leaves.v.size() == leaves.cap) leaves.bottom()->newp.reset();
-          leaves.push(c);
-        } else {
-          c->oldp.reset();
-          c->newp.reset();
+        // the extension's score needs nothing of the child: test it against the beam's bottom BEFORE the child is looked up
+        // or created (an inactive child that fails the test is left as it is: nothing reads it until it becomes a leaf)
+        const float prev = (lab == b->label) ? b->oldp.blank : b->oldp.total;
+        Prob np;
+        np.blank = kLogZero;
+        np.label = lp[lab] + prev;
+        np.total = np.label;
+        if (!candidate(np)) {
+          // (TF's decoder clears BOTH probabilities of a child that fails here.  That matters for one kind of child: one that
+          //  was a leaf of this frame, was evicted above and is still to come in this loop - cleared, it grows no children)
+          Entry* e = b->kids ? b->kids[lab] : nullptr;
+          if (e && !e->active()) e->oldp.reset();
+          continue;
         }
+        Entry* c = arena.child(b, lab);
+        if (c->active()) continue;
+        c->newp = np;
+        if (leaves.v.size() == leaves.cap) leaves.bottom()->newp.reset();
+        leaves.push(c);
       }
     }
   }

@@ -1367,8 +1367,9 @@ int weight_grads(nasr_ctx* h, int l, hipStream_t ws, bool side) {
   // The side instantiation splits K exactly as the main one would: every output element then sums the same k-blocks in
   // the same order whatever the tile shape - the gradients are bitwise those of the serial order.  (NASR_SIDE_SPLIT=own:
   // the split its own cost model picks, for the A/B logs.)
-  static const bool own_split = [] { const char* e = getenv("NASR_SIDE_SPLIT"); return e && e[0] == 'o'; }();
-  const bool side_split = side && own_split;
+  static const int split_mode = [] { const char* e = getenv("NASR_SIDE_SPLIT"); return !e ? 0 : e[0] == 'o' ? 1 : e[0] == '1' ? 2 : 0; }();
+  const bool side_split = side && split_mode == 1;
+  const bool side_one = side && split_mode == 2;       // (A/B logs: no K split at all on the side stream)
   // one pass over dG: its transposed planes + 64-row partial column sums (already there when gemm_dx(l) ran)
   if (h->gttp_layer != l) {
     dg_scales(h, l, R, false, ws);
@@ -1389,7 +1390,7 @@ int weight_grads(nasr_ctx* h, int l, hipStream_t ws, bool side) {
     g.B = GT; g.C = h->G + h->off_wx[l];
     g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
     g.side = side;
-    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K, 1, side_split);
+    g.split_k = side_one ? 1 : gemm_tph_pick_split(g.M, g.N, g.K, 1, side_split);
     g.slabs = slabs_for(g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
     pl_gemm(g, ai.cinv, gc.ip(), ws);
@@ -1405,7 +1406,7 @@ int weight_grads(nasr_ctx* h, int l, hipStream_t ws, bool side) {
     g.c_bstride = (int64_t)Hp * N4;            // off_u[l*D + 1] - off_u[l*D] (build_layout)
     g.a_kshift1 = Bp;
     g.side = side;
-    g.split_k = gemm_tph_pick_split(g.M, g.N, g.K, D, side_split);
+    g.split_k = side_one ? 1 : gemm_tph_pick_split(g.M, g.N, g.K, D, side_split);
     g.slabs = slabs_for(g.split_k * D, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
     pl_gemm(g, ao.cinv, gc.ip(), ws, Hp, N4);
