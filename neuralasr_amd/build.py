@@ -8,8 +8,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libnasr.so')
-SOURCES = ['gemm.hip', 'gemm_tph.hip', 'lstm.hip', 'lstm_persist.hip', 'lstm_wide.hip', 'ctc.hip', 'dense.hip', 'optim.hip', 'nasr_api.hip', 'beam.cpp']
-HEADERS = [os.path.join(CSRC, 'kernels.h'), os.path.join(HERE, '..', 'include', 'nasr.h')]
+SOURCES = ['gemm.hip', 'gemm_tph.hip', 'lstm.hip', 'lstm_persist.hip', 'lstm_wide.hip', 'ctc.hip', 'dense.hip', 'optim.hip', 'nasr_layout.hip',
+           'nasr_batch.hip', 'nasr_pass.hip', 'nasr_api.hip', 'nasr_comm.hip', 'beam.cpp']
+HEADERS = [os.path.join(CSRC, 'kernels.h'), os.path.join(CSRC, 'nasr_ctx.h'), os.path.join(HERE, '..', 'include', 'nasr.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 

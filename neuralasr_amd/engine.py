@@ -270,8 +270,16 @@ class Engine:
             raise _lib.NasrError(rc, 'nasr_label_error_rate: bad arguments')
         return float(out.value)
 
-    def set_step_decode(self, on):
-        self._ck(self.lib.nasr_set_step_decode(self.h, int(bool(on))))
+    def set_step_decode(self, on, logits=False):
+        """Greedy decode of every step's logits (on) and, with logits=True, a copy of the logits themselves for the host
+        (include/nasr.h: nasr_set_step_decode, nasr_get_step_logits)."""
+        self._ck(self.lib.nasr_set_step_decode(self.h, (1 if on else 0) | (2 if (on and logits) else 0)))
+
+    def step_logits(self, B, T):
+        """[T',B,C] logits of the step just enqueued, as soon as its forward pass + CTC are done (the backward pass runs on)."""
+        out = np.empty((self.logit_frames(T), B, self.num_classes), np.float32)
+        self._ck(self.lib.nasr_get_step_logits(self.h, _fp(out)))
+        return out
 
     def get_decoded(self, B, T):
         Tp = self.logit_frames(T)

@@ -3,10 +3,11 @@ numpy-out train / validate / evaluate / decode, checkpoints, and data-parallel t
 arithmetic step in the HIP library behind include/nasr.h (no TensorFlow, no CPU fallback).
 
 Differences from the reference that a caller can observe, all deliberate and documented in DESIGN.md:
-  * validate() / evaluate() / decode() use the reference's decoder (ctc_beam_search_decoder, width 100,
-    merge_repeated, host C++); the `mean_ler` that train() returns with every step uses the greedy decoder
-    the reference names in the comment at tfnetwork.py:62-63 (`train_ler_decoder = 'beam'` switches it, at
-    the price of a second forward pass and a CPU beam search per step);
+  * train() / validate() / evaluate() / decode() all use the reference's decoder (ctc_beam_search_decoder, width 100,
+    merge_repeated, host C++).  The `mean_ler` of a training step is decoded from the step's own logits, copied out
+    behind the CTC kernels, while the device runs the backward pass; train_model does not even wait for it - it
+    collects the steps' LERs when it logs (`train_ler_decoder = 'greedy'` switches to the greedy decoder the
+    reference names in the comment at tfnetwork.py:62-63: no host work at all);
   * num_gpus > 1 means one process per GPU (torch.distributed.run); inside a single process the towers are
     time-sliced on one GPU with the same split / averaging arithmetic;
   * checkpoints are `model-<step>.npz` (flat fp32 params + Adam m, v + step) with TF Saver's cadence and
@@ -50,7 +51,7 @@ class HipNetwork(Network):
     merge = 'stack_reshape'
     keep_checkpoints = 5                     # tf.train.Saver() default max_to_keep
     decoder = 'beam'                         # validate / evaluate / decode: tf.nn.ctc_beam_search_decoder defaults
-    train_ler_decoder = 'greedy'             # mean_ler of train(): greedy on the step's own logits
+    train_ler_decoder = 'beam'               # mean_ler of train(): the reference's decoder on the step's own logits ('greedy': on the device)
     beam_width = 100
     device_context = True                    # rebuild include_context's stacking on the GPU (1/(2c+1) of the H2D bytes)
     bucketed_allreduce = True                # one process per GPU: exchange per-layer gradient buckets under the backward pass
@@ -85,6 +86,7 @@ class HipNetwork(Network):
         self._staged_lock = threading.Lock()
         self._pending = None                    # the batch of the last fast-path step, until that step is known not to be void
         self._begun = None                      # begin_step() without its finish_step() yet
+        self._pool = None                       # host threads that decode the steps' logits (train_ler_decoder = 'beam')
         self.global_step = self.config.start_step
         self.load_checkpoint(self.global_step if fortraining else 1, self.config.model_dir)
         if fortraining and self.coll.rank == 0:
@@ -223,21 +225,27 @@ class HipNetwork(Network):
         next batch inside the timed step with the device idle, train.py:23-26)."""
         self.global_step += 1
         n, mine = self._towers()
-        if self.async_step and len(mine) == 1 and self.train_ler_decoder == 'greedy':
+        if self.async_step and len(mine) == 1:
             f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, mine[0])
             batch = (mfccs, f, l, s, ll, n)
             self._begun = ('async', (batch, self._enqueue_step(*batch)))
         else:
             self._begun = ('sync', (mfccs, labels, seq_len, labels_len))
 
-    def finish_step(self):
+    def finish_step(self, lazy=False):
         """Second half of train(): (loss, mean_ler) of the step begun last - available after its forward pass + CTC; the
-        device may still be in its backward pass when this returns."""
+        device may still be in its backward pass when this returns.  lazy=True: mean_ler may come back as a handle with a
+        .result() (the beam search of the step's logits still runs on host threads) - for a caller like train_model, which
+        only needs the LERs when it logs; multi-process runs average such a window with mean_over_ranks()."""
         kind, batch = self._begun
         self._begun = None
         if kind == 'async':
-            return self._finish_async(*batch)
+            return self._finish_async(*batch, lazy=lazy)
         return self._train_sync(*batch)
+
+    def mean_over_ranks(self, value):
+        """Mean of a host float over the towers' processes (reduce_mean of tfnetwork.py:135-136); the value itself with one."""
+        return self.coll.mean_scalars([value])[0] if self.coll.world > 1 else float(value)
 
     def _train_sync(self, mfccs, labels, seq_len, labels_len):
         self._settle()
@@ -261,6 +269,7 @@ class HipNetwork(Network):
         elif not (self._use_device_context() and
                   self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
             self.engine.upload_batch(f, s, l, ll)
+        self.engine.set_step_decode(True, logits=self.train_ler_decoder == 'beam')
         self.engine.compute_grads()
         if self.coll.world > 1:
             if self._grad_tensor is None:
@@ -273,6 +282,24 @@ class HipNetwork(Network):
         self.engine.apply_adam(1.0 / n)
         return self.engine.step_token()
 
+    # ------------------------------------------------------------------ the step's LER (tfnetwork.py:61-70)
+    def _beam_ler(self, logits, s, l, ll):
+        hyps = self.engine.beam_search(logits, s, self.beam_width, merge_repeated=True)[0]
+        return self.engine.label_error_rate(hyps, l, ll)
+
+    def _step_ler(self, hyps, f, l, s, ll, lazy):
+        """mean_ler of the step just enqueued: greedy from the device's decode, or the reference's beam search on the step's
+        own logits - on a host thread (the C++ decoder runs one thread per utterance and holds no interpreter lock)."""
+        if self.train_ler_decoder != 'beam':
+            return self.engine.label_error_rate(hyps, l, ll)
+        logits = self.engine.step_logits(len(s), f.shape[1])
+        if not lazy:
+            return self._beam_ler(logits, s, l, ll)
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix='nasr-beam')
+        return self._pool.submit(self._beam_ler, logits, s, l, ll)
+
     def _redo_step(self, batch, why):
         """A void step's batch again, start to finish, until it counts; returns the (loss, mean_ler) of the attempt that
         did.  Every rank takes this path at the same point of its call sequence and runs the same number of attempts: the
@@ -281,9 +308,10 @@ class HipNetwork(Network):
         for attempt in range(3):
             self.logger.warning('%s: repeating its batch' % why)
             token = self._enqueue_step(None, f, l, s, ll, n)
-            loss, _, hyps = self.engine.step_results(len(s), f.shape[1])
+            loss, fault, hyps = self.engine.step_results(len(s), f.shape[1])
+            ler = float('nan') if fault else self._step_ler(hyps, f, l, s, ll, lazy=False)
             if not self.engine.settle_token(token):
-                return loss, self.engine.label_error_rate(hyps, l, ll)
+                return loss, ler
         raise RuntimeError('a training step stayed void after 3 attempts')
 
     def _settle(self):
@@ -294,7 +322,7 @@ class HipNetwork(Network):
             if self.engine.settle_token(token):
                 self._redo_step(batch, 'the last training step was void (persistent recurrence aborted on some rank)')
 
-    def _finish_async(self, batch, token):
+    def _finish_async(self, batch, token, lazy=False):
         mfccs, f, l, s, ll, n = batch
         loss, fwd_fault, hyps = self.engine.step_results(len(s), f.shape[1])
         if fwd_fault:
@@ -302,7 +330,7 @@ class HipNetwork(Network):
             # (the fault word travels with the gradients); it is repeated where every rank notices it.
             loss, ler = float('nan'), float('nan')
         else:
-            ler = self.engine.label_error_rate(hyps, l, ll)
+            ler = self._step_ler(hyps, f, l, s, ll, lazy)
         # the step BEFORE this one has ended by now (stream order): was it void?
         prev, self._pending = self._pending, (batch, token)
         if prev is not None and self.engine.settle_token(prev[1]):
@@ -318,6 +346,11 @@ class HipNetwork(Network):
             self._pending = None
             self.engine.settle_token(token)
             loss, ler = self._redo_step(batch, 'step %d was void (persistent recurrence aborted)' % self.global_step)
+        if hasattr(ler, 'result'):
+            # lazy: the LER is still being decoded; the caller averages its window over the ranks (mean_over_ranks)
+            if self.coll.world > 1:
+                loss = self.coll.mean_scalars([loss])[0]
+            return np.float32(loss), ler
         if self.coll.world > 1:
             # (a rank-local forward fault leaves NaN here on every rank: train_model keeps such a step out of its means;
             # the step itself is repeated one call later, where every rank sees the fault word)
@@ -382,6 +415,7 @@ class HipNetwork(Network):
             elif not (self._use_device_context() and
                       self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
                 self.engine.upload_batch(f, s, l, ll)
+            self.engine.set_step_decode(True, logits=self.train_ler_decoder == 'beam')
             self.engine.compute_grads()
             if self.coll.world > 1 and self.bucketed_allreduce:
                 # enqueue the exchange NOW, before the host waits for the loss: bucket i goes out as soon as the backward
@@ -394,7 +428,7 @@ class HipNetwork(Network):
                     reduced = True
             # One tower in this process: the optimiser step is enqueued BEFORE the host waits for the loss, so the GPU
             # does not idle through the host's wake-up (Adam is a no-op on the device if the step turns out void)
-            early_adam = len(mine) == 1 and self.train_ler_decoder != 'beam'
+            early_adam = len(mine) == 1
             if early_adam:
                 if self.coll.world > 1 and not reduced:
                     if self._grad_tensor is None:
@@ -406,9 +440,8 @@ class HipNetwork(Network):
             # them); the step is repeated by train()
             try:
                 loss = self.engine.get_loss()
-                hyps = (self._decode(f, s, 'beam') if self.train_ler_decoder == 'beam'
-                        else self.engine.get_decoded(len(s), f.shape[1]))
-                ler = self.engine.label_error_rate(hyps, l, ll)
+                hyps = None if self.train_ler_decoder == 'beam' else self.engine.get_decoded(len(s), f.shape[1])
+                ler = self._step_ler(hyps, f, l, s, ll, lazy=False)     # beam: from the step's own logits, no second pass
             except NasrError as exc:
                 if not self._is_abort(exc):
                     raise

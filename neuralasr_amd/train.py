@@ -25,16 +25,27 @@ def train_model(dataTrain, datavalid, config, prefetch=2):
     spent, loss_sum, ler_sum = 0.0, 0.0, 0.0     # train_time_sec is never reset (train.py:20,26,34)
     counted = 0                                  # steps of the window whose values count (all of them, normally)
     split = prefetch and all(hasattr(network, a) for a in ('begin_step', 'finish_step', 'stage_batch'))
+    lazy_ok = split and hasattr(network, 'mean_over_ranks')      # finish_step(lazy=True) is HipNetwork's
+
+    window = []                                   # (loss, mean_ler or a handle with .result()) of the steps since the last log line
 
     def report(loss, mean_ler):
         nonlocal loss_sum, ler_sum, counted
-        # a step whose forward pass was void on some rank (HipNetwork: a persistent-recurrence abort, repeated one call
-        # later) reports NaN on every rank: it stays out of the window's means instead of turning them into NaN
-        if loss == loss and mean_ler == mean_ler:
-            loss_sum += loss
-            ler_sum += mean_ler
-            counted += 1
+        window.append((loss, mean_ler))
         if network.global_step % config.report_step == 0:
+            lazy = False
+            for lo, le in window:
+                if hasattr(le, 'result'):             # HipNetwork: the step's beam search ran on host threads meanwhile
+                    le, lazy = le.result(), True
+                # a step whose forward pass was void on some rank (HipNetwork: a persistent-recurrence abort, repeated one
+                # call later) reports NaN on every rank: it stays out of the window's means instead of turning them into NaN
+                if lo == lo and le == le:
+                    loss_sum += lo
+                    ler_sum += le
+                    counted += 1
+            del window[:]
+            if lazy and hasattr(network, 'mean_over_ranks'):
+                ler_sum = network.mean_over_ranks(ler_sum)     # lazily decoded LERs are local until here (one collective per log line)
             network.save_checkpoint()
             # train.py:32-34 divides by report_step; `counted` equals it unless a void step was left out
             den = counted if 0 < counted < config.report_step else config.report_step
@@ -63,7 +74,7 @@ def train_model(dataTrain, datavalid, config, prefetch=2):
             nxt = next(it, None)                          # loaded, padded and staged under the step the device is running
             if nxt is not None:
                 network.stage_batch(*nxt)
-            loss, mean_ler = network.finish_step()
+            loss, mean_ler = network.finish_step(lazy=True) if lazy_ok else network.finish_step()
             spent += time.time() - t0
             report(loss, mean_ler)
             t0 = time.time()

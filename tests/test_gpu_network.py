@@ -51,7 +51,9 @@ def test_load_network_by_reference_name_and_train_two_towers(tmp_path):
     lers = []
     for sl in O.shard_slices(4, 2):
         lg, _ = O.network_forward(spec, params, mfccs[sl], [int(s) for s in seq_len[sl]])
-        hy = O.greedy_decode(lg, [int(s) for s in seq_len[sl]])
+        # the mean_ler of a training step is the reference's: ctc_beam_search_decoder defaults (tfnetwork.py:61-70,188-189)
+        lens = [int(s) for s in seq_len[sl]]
+        hy = [O.ctc_beam_search(lg[:lens[b], b], 100, True)[0] for b in range(len(lens))]
         lers.append(O.label_error_rate(hy, labels[sl], labels_len[sl]))
     newp, _, _ = O.adam_tf(params, grads_o, [0 * p for p in params], [0 * p for p in params], 1, cfg.learningrate)
     loss, ler = net.train(mfccs, labels, seq_len, labels_len)
@@ -506,3 +508,60 @@ def test_step_tokens_name_the_optimiser_steps(tmp_path):
         e.settle_token(2)
     with pytest.raises(_lib.NasrError, match='no such step'):
         e.settle_token(7)
+
+
+def test_train_ler_is_the_beam_search_of_the_steps_own_logits_lazily_or_not(tmp_path):
+    """tfnetwork.py:188-189 fetches mean_ler = the LER of the width-100 beam decode with every step.  HipNetwork decodes the
+    step's own logits (copied out behind the CTC kernels) on host threads: train() waits for it, finish_step(lazy=True)
+    hands back a handle that train_model resolves when it logs - same numbers either way, equal to the oracle's beam LER of
+    the parameters the step started from; 'greedy' switches to the device's greedy decode."""
+    cfg = Config(make_config(tmp_path, num_gpus='1', batch_size='4'), True)
+    net = cfg.load_network(fortraining=True)
+    assert net.train_ler_decoder == 'beam'
+    spec = spec_of(net, cfg)
+    ds = DataSet(cfg.train_input, cfg)
+    batch = ds.get_next_batch()
+    mfccs, labels, seq_len, labels_len = batch
+    lens = [int(s) for s in seq_len]
+
+    def oracle_lers():
+        params = [p.astype(np.float64) for p in O.unflatten(spec, net.engine.get_params())]
+        lg, _ = O.network_forward(spec, params, mfccs, lens)
+        beam = [O.ctc_beam_search(lg[:lens[b], b], 100, True)[0] for b in range(len(lens))]
+        return (O.label_error_rate(beam, labels, labels_len), O.label_error_rate(O.greedy_decode(lg, lens), labels, labels_len))
+    want_beam, _ = oracle_lers()
+    _, ler = net.train(*batch)
+    assert float(ler) == pytest.approx(want_beam, abs=1e-6)
+    net.save_checkpoint()                                   # settles the step: the parameters are those after one update
+    want_beam, _ = oracle_lers()
+    net.begin_step(*batch)
+    loss, handle = net.finish_step(lazy=True)
+    assert hasattr(handle, 'result') and isinstance(loss, np.float32)
+    assert float(handle.result()) == pytest.approx(want_beam, abs=1e-6)
+    net.save_checkpoint()
+    net.train_ler_decoder = 'greedy'
+    _, want_greedy = oracle_lers()
+    _, ler = net.train(*batch)
+    assert float(ler) == pytest.approx(want_greedy, abs=1e-6)
+
+
+def test_train_model_logs_the_beam_ler_of_every_step(tmp_path, caplog):
+    """The log line of train.py:32-34 averages the steps' mean_ler: with the lazily decoded LERs it must show the same number
+    as a loop that waits for every step's beam search."""
+    import logging
+    from neuralasr_amd import train as train_mod
+    cfgs = [Config(make_config(tmp_path, num_gpus='1', batch_size='2', report_step='3', epochs='2',
+                               model_dir=str(tmp_path / ('lz%d' % k))), True) for k in range(2)]
+    ref = cfgs[1].load_network(fortraining=True)
+    ds = DataSet(cfgs[1].train_input, cfgs[1])
+    lers = []
+    for _ in range(cfgs[1].epochs):
+        while ds.has_more_batches():
+            lers.append(float(ref.train(*ds.get_next_batch())[1]))
+        ds.reset_epoch()
+    with caplog.at_level(logging.INFO, logger='NeuralASR'):
+        train_mod.train_model(DataSet(cfgs[0].train_input, cfgs[0]), None, cfgs[0])
+    lines = [r.getMessage() for r in caplog.records if r.getMessage().startswith('Step: ')]
+    assert len(lines) == len(lers) // 3 and len(lines) >= 1
+    for i, ln in enumerate(lines):
+        assert ', ler = %.4f' % np.mean(lers[3 * i:3 * i + 3]) in ln, (ln, lers)

@@ -82,9 +82,14 @@ def main():
         with open(cfgp, 'w') as fh:
             fh.write(CONFIG % dict(out=out, epochs=epochs, network=network, batch=batch))
         steps_per_epoch = (n_utt + batch - 1) // batch
-        for label, prefetch in (('overlapped loop: next batch loaded + staged under the running step', 2),
-                                ('reference order: load, upload, train', 0),
-                                ('overlapped loop, again', 2)):
+        from neuralasr_amd.networks.hipnetwork import HipNetwork
+        for label, prefetch, decoder in (
+                ('overlapped loop (next batch loaded + staged under the running step), mean_ler by beam search on host threads', 2, 'beam'),
+                ('the same with the greedy decoder on the device', 2, 'greedy'),
+                ('reference order: load, upload, train (beam search waited for in every step)', 0, 'beam'),
+                ('overlapped loop, beam, again', 2, 'beam'),
+                ('overlapped loop, greedy, again', 2, 'greedy')):
+            HipNetwork.train_ler_decoder = decoder
             cfg = Config(cfgp, True)
             stamps = []
             net_cls = cfg.load_network.__func__
@@ -94,8 +99,8 @@ def main():
                 for name in ('train', 'finish_step'):
                     inner = getattr(net, name)
 
-                    def timed(*a, _inner=inner, _name=name):
-                        r = _inner(*a)
+                    def timed(*a, _inner=inner, _name=name, **kw):
+                        r = _inner(*a, **kw)
                         if _name == 'finish_step':
                             stamps.append(time.perf_counter())
                         return r
@@ -108,7 +113,7 @@ def main():
             dt = (stamps[-1] - stamps[warm]) / (len(stamps) - 1 - warm)
             gaps = np.diff(np.asarray(stamps)) * 1e3
             med = float(np.median(gaps[warm:]))
-            print('%-72s mean %.3f ms, median %.3f ms per step  (%d steps of %d frames: %.3f M frames/s at the median)'
+            print('%-112s mean %.3f ms, median %.3f ms per step  (%d steps of %d frames: %.3f M frames/s at the median)'
                   % (label, dt * 1e3, med, len(stamps) - 1 - warm, 500 * batch, 500 * batch / med / 1e3), flush=True)
             print('   step-to-step gaps (ms): ' + ' '.join('%.1f' % g for g in gaps), flush=True)
         if os.environ.get('NASR_E2E_TIMERS'):
@@ -129,7 +134,7 @@ def main():
                         d[1] += 1
                 setattr(Engine, name, timed)
                 return orig
-            names = ['stage_batch', 'commit_batch', 'compute_grads', 'apply_adam', 'step_results', 'settle_step',
+            names = ['stage_batch', 'commit_batch', 'compute_grads', 'apply_adam', 'step_results', 'settle_step', 'settle_token', 'step_logits', 'beam_search', 'set_step_decode',
                      'label_error_rate', 'upload_batch_context', 'upload_batch']
             origs = {nm: wrap(nm) for nm in names if hasattr(Engine, nm)}
             gnb = DataSet.get_next_batch
