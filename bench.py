@@ -538,6 +538,21 @@ def main():
         acc = pt if acc is None else {k: (acc[k] + v if k.endswith('_ms') else v) for k, v in pt.items()}
     eng.set_profiling(False)
     phases = {k: (v / NP if k.endswith('_ms') else v) for k, v in acc.items()}
+    # With the weight gradients of the upper layers co-running (the default where it applies), the persistent BPTT launches
+    # share their CUs: a few more profiled steps WITHOUT the overlap give the dominant kernel's duration on its own.
+    alone = None
+    if getattr(eng, 'wgrad_overlap', False):
+        eng.set_wgrad_overlap(False)
+        step()
+        eng.set_profiling(True)
+        acc2 = None
+        for _ in range(NP):
+            step()
+            pt = eng.phase_times()
+            acc2 = pt if acc2 is None else {k: (acc2[k] + v if k.endswith('_ms') else v) for k, v in pt.items()}
+        eng.set_profiling(False)
+        eng.set_wgrad_overlap(True)
+        alone = {k: (v / NP if k.endswith('_ms') else v) for k, v in acc2.items()}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -585,6 +600,7 @@ def main():
                        'batch_per_gpu': B, 'frames': T, 'var_len': bool(args.var_len),
                        'parallelism': f'dp{world}', 'hipgraph': not args.no_graph,
                        'recurrence': eng.recurrence_mode,
+                       'wgrad_overlap': bool(getattr(eng, 'wgrad_overlap', False)),
                        'recurrence_forward_mfma': ('fp32 products from 2 fp16 planes of U and 2 fp16 parts of h (4x4x4 f16 MFMA)'
                                                    if os.environ.get('NASR_REC', 'f16') != 'f32' else 'fp32 4x4x1 MFMA'),
                        'gemm': 'fp32 products from 2 fp16 planes x 3 MFMA products, fp32 accumulation, power-of-two '
@@ -627,6 +643,17 @@ def main():
                                     'note': 'the next batch staged through pinned memory on the copy stream while the '
                                             'step runs (nasr_stage_batch + nasr_commit_batch)'}},
         }
+        if alone is not None:
+            # `roofline` prices the dominant kernel as it runs in the timed steps - sharing its CUs with the side-stream weight-
+            # gradient GEMMs (the step is faster for it, the launch slower).  The same kernel on its own:
+            a_bwd_us = alone['rec_bwd_ms'] * 1e3 / max(alone['rec_bwd_launches'], 1)
+            a_fwd_us = alone['rec_fwd_ms'] * 1e3 / max(alone['rec_fwd_launches'], 1)
+            a_us, a_bytes = (a_bwd_us, bb * spl / dpl) if dom_bwd else (a_fwd_us, fb * spl / dpl)
+            out['roofline']['alone'] = {'us_per_launch': a_us, 'achieved': a_bytes / (a_us * 1e-6) / 1e9,
+                                        'frac': a_bytes / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 'step_us': a_us / spl,
+                                        'phases_ms': {k: round(v, 4) for k, v in alone.items() if k.endswith('_ms')},
+                                        'note': 'the same launches with nasr_set_wgrad_overlap(0): nothing shares their CUs '
+                                                '(3 profiled steps after the timed ones); the timed steps run WITH the overlap'}
         if wide:
             # The wide kernels keep the recurrent matrix resident for the whole launch, so SURVEY §8d's per-timestep bytes
             # (which re-price it every step) exceed what any memory system could deliver in the launch's time: quoted as

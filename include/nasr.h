@@ -209,7 +209,13 @@ int nasr_apply_adam(nasr_handle h, float grad_scale);
  * backward pass, tfnetwork.py:72-86): waits on `hip_stream` for bucket i like nasr_grad_bucket_wait, then launches there a
  * kernel shaped like a ring all-reduce step over that bucket - nblocks workgroups of 256 threads, each sweeping its slice
  * `passes` times with 16-byte loads and stores, the data unchanged.  tools/rccl_standin.py, tests/test_gpu_persist.py. */
-int nasr_diag_bucket_traffic(nasr_handle h, int i, void* hip_stream, int nblocks, int passes); /* g*grad_scale, TF Adam, step += 1 (async) */
+int nasr_diag_bucket_traffic(nasr_handle h, int i, void* hip_stream, int nblocks, int passes);
+/* The gradients of tfnetwork.py:120-128 are a set: nothing orders dW(l) before the backward pass of layer l-1.  With the
+ * persistent recurrence, 500-wide layers and more than one layer, layer l's weight gradients run on a side stream beside the
+ * persistent BPTT launch of layer l-1 (bitwise the gradients of the serial order).  On by default
+ * (NASR_WGRAD_OVERLAP=0 at nasr_create turns it off); nasr_set_wgrad_overlap switches it for A/B measurements. */
+int nasr_set_wgrad_overlap(nasr_handle h, int enabled);
+int nasr_get_wgrad_overlap(nasr_handle h); /* g*grad_scale, TF Adam, step += 1 (async) */
 /* copy the gradients out (TF order) / load externally reduced gradients (TF order) for nasr_apply_adam:
  * the single-process form of average_gradients (several towers time-sliced on one GPU). */
 int nasr_get_grads(nasr_handle h, float* flat, int64_t n);

@@ -31,6 +31,7 @@ SYMBOLS = [
     'nasr_discard_batch', 'nasr_set_bucket_defer', 'nasr_comm_unique_id', 'nasr_comm_init', 'nasr_comm_size',
     'nasr_comm_allreduce_grads', 'nasr_comm_mean', 'nasr_comm_destroy', 'nasr_get_step_results', 'nasr_settle_step',
     'nasr_step_token', 'nasr_settle_token', 'nasr_diag_bucket_traffic', 'nasr_get_step_logits',
+    'nasr_set_wgrad_overlap', 'nasr_get_wgrad_overlap',
 ]
 
 
@@ -138,6 +139,8 @@ def load():
         'nasr_settle_token': (c_int, [H, c_int64, POINTER(c_int)]),
         'nasr_diag_bucket_traffic': (c_int, [H, c_int, c_void_p, c_int, c_int]),
         'nasr_get_step_logits': (c_int, [H, fp]),
+        'nasr_set_wgrad_overlap': (c_int, [H, c_int]),
+        'nasr_get_wgrad_overlap': (c_int, [H]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

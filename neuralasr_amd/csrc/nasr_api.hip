@@ -246,10 +246,11 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   if (hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking) != hipSuccess) return bail(NASR_ERR_HIP, "hipStreamCreate (copy stream) failed");
   {
     const char* eo = getenv("NASR_WGRAD_OVERLAP");
-    h->wg_overlap = !(eo && eo[0] == '0') && h->persist && h->Hp == 512 && h->L > 1;   // on unless NASR_WGRAD_OVERLAP=0
+    const bool eligible = h->persist && h->Hp == 512 && h->L > 1;
+    h->wg_overlap = eligible && !(eo && eo[0] == '0');          // on unless NASR_WGRAD_OVERLAP=0 (nasr_set_wgrad_overlap)
     h->ev_wg.assign(h->L, nullptr);
     h->wg_pending.assign(h->L, 0);
-    if (h->wg_overlap) {
+    if (eligible) {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = lowest priority (largest number)
       if (hipStreamCreateWithPriority(&h->wst, hipStreamNonBlocking, lo) != hipSuccess ||
@@ -866,6 +867,18 @@ int nasr_set_recurrence_mode(nasr_handle h, int persistent) {
   h->persist_wanted = h->persist;
   return repack(h);
 }
+
+int nasr_set_wgrad_overlap(nasr_handle h, int enabled) {
+  if (!h) return NASR_ERR_ARG;
+  if (enabled && !h->wst) return h->fail(NASR_ERR_STATE, "the weight-gradient side stream was not set up for this handle "
+                                                         "(needs the persistent recurrence at Hp = 512 and more than one layer)");
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  h->wg_overlap = enabled != 0;
+  if (h->resident) return ensure_shape(h, h->B, h->T, h->Lmax);     // the side stream's own copies of the dG planes
+  return NASR_OK;
+}
+
+int nasr_get_wgrad_overlap(nasr_handle h) { return h && h->wg_overlap ? 1 : 0; }
 
 int nasr_set_bucket_defer(nasr_handle h, int defer) {
   if (!h) return NASR_ERR_ARG;

@@ -120,7 +120,7 @@ bool pinned_ensure(void** p, size_t* cap, size_t bytes) {
   *p = nullptr;
   *cap = 0;
   const size_t want = bytes + bytes / 8;
-  if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) return false;
+  if (hipHostMalloc(p, want, hipHostMallocMapped) != hipSuccess) return false;   // (kernels write step results into it)
   *cap = want;
   return true;
 }

@@ -341,6 +341,8 @@ bool persist_census(nasr_ctx* h);
 void persist_rearm(nasr_ctx* h);
 // a word in host-mapped pinned memory written in stream order (and, with f0_dst, a device float copied beside it)
 void launch_stamp(unsigned* dst, unsigned value, float* f0_dst, const float* f0_src, hipStream_t st);
+void launch_publish_results(const float* loss, const float* fault, const int* lens, int Bp, const int* ids, int n_ids, void* host,
+                            unsigned* stamp, unsigned value, hipStream_t st);
 bool wait_stamp(const uint32_t* w, uint32_t want, double timeout_s);
 int sync_checked(nasr_ctx* h);
 void drop_graphs(nasr_ctx* h);

@@ -117,6 +117,28 @@ void launch_stamp(unsigned* dst, unsigned value, float* f0_dst, const float* f0_
   hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, dst, value, f0_dst, f0_src);
 }
 
+// The values a step returns to the host (loss, fault word, greedy decode), written by ONE kernel straight into the host's
+// pinned result buffer and stamped behind them - instead of four small device-to-host copies and a stamp launch per step.
+// host: [loss f32][fault f32][lens i32 x Bp][ids i32 x n_ids]
+__global__ __launch_bounds__(256) void publish_results_kernel(const float* __restrict__ loss, const float* __restrict__ fault,
+                                                              const int* __restrict__ lens, int Bp, const int* __restrict__ ids,
+                                                              int n_ids, unsigned* host, unsigned* stamp, unsigned value) {
+  if (threadIdx.x == 0) {
+    host[0] = __float_as_uint(*loss);
+    host[1] = __float_as_uint(*fault);
+  }
+  for (int i = threadIdx.x; i < Bp; i += 256) host[2 + i] = (unsigned)lens[i];
+  for (int i = threadIdx.x; i < n_ids; i += 256) host[2 + Bp + i] = (unsigned)ids[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(stamp, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish_results(const float* loss, const float* fault, const int* lens, int Bp, const int* ids, int n_ids, void* host,
+                            unsigned* stamp, unsigned value, hipStream_t st) {
+  hipLaunchKernelGGL(publish_results_kernel, dim3(1), dim3(256), 0, st, loss, fault, lens, Bp, ids, n_ids,
+                     static_cast<unsigned*>(host), stamp, value);
+}
+
 bool wait_stamp(const uint32_t* w, uint32_t want, double timeout_s) {
   const volatile uint32_t* v = w;
   for (int i = 0; i < 4000; ++i)

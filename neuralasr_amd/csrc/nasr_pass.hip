@@ -298,16 +298,13 @@ int ctc_forward(nasr_ctx* h) {
     const size_t bytes = lg_off + lg_bytes;
     if (!pinned_ensure(&r.host, &r.cap, bytes)) return h->fail(NASR_ERR_HIP, "hipHostMalloc of the step results failed");
     char* hp = static_cast<char*>(r.host);
-    HIPCHK(h, hipMemcpyAsync(hp, h->loss.p, 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(h, hipMemcpyAsync(hp + 4, h->Gbase, 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(h, hipMemcpyAsync(hp + 8, h->lens.p, (size_t)h->Bp * 4, hipMemcpyDeviceToHost, h->st));
-    HIPCHK(h, hipMemcpyAsync(hp + 8 + (size_t)h->Bp * 4, h->ids.p, (size_t)h->B * h->Tp * 4, hipMemcpyDeviceToHost, h->st));
     // the step's logits too (before the CTC gradient overwrites them in place): what tf.nn.ctc_beam_search_decoder reads in
     // the reference's train step (tfnetwork.py:61-64,188-189) - the host decodes them while the device runs on
     if (lg_bytes) HIPCHK(h, hipMemcpyAsync(hp + lg_off, h->logits.p, lg_bytes, hipMemcpyDeviceToHost, h->st));
     r.logits = lg_bytes != 0;
     r.seq = ++h->stamp_seq;
-    launch_stamp(r.stamp, r.seq, (float*)nullptr, (const float*)nullptr, h->st);
+    launch_publish_results(h->loss.as<float>(), h->Gbase, h->lens.as<int>(), h->Bp, h->ids.as<int>(), h->B * h->Tp, r.host, r.stamp,
+                           r.seq, h->st);
     r.valid = true; r.B = h->B; r.Bp = h->Bp; r.Tp = h->Tp;
   }
   HIPCHK(h, hipGetLastError());

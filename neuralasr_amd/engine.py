@@ -334,6 +334,14 @@ class Engine:
         self._ck(self.lib.nasr_settle_step(self.h, int(bool(previous)), byref(v)))
         return bool(v.value)
 
+    @property
+    def wgrad_overlap(self):
+        """True when the upper layers' weight gradients run beside the persistent BPTT launch of the layer below."""
+        return bool(self.lib.nasr_get_wgrad_overlap(self.h))
+
+    def set_wgrad_overlap(self, on):
+        self._ck(self.lib.nasr_set_wgrad_overlap(self.h, int(bool(on))))
+
     def diag_bucket_traffic(self, i, stream, nblocks, passes):
         """Diagnostics: a ring-all-reduce-shaped kernel over bucket i on `stream`, behind the bucket's event (include/nasr.h)."""
         from ctypes import c_void_p

@@ -292,3 +292,41 @@ def test_no_abort_beside_a_cu_resident_collective_stand_in():
         assert e.persist_stats() == (0, 0) and e.recurrence_mode == 'persistent'
         e.close()
         ref.close()
+
+
+def test_side_stream_weight_gradients_are_bitwise_the_serial_ones():
+    """with 500-wide layers and more than one layer, layer l's weight gradients run on a side stream beside the
+    persistent BPTT launch of layer l-1, in a 3-wave GEMM instantiation with another tile shape - and with the K split of the
+    serial order, so every gradient element sums the same k-blocks in the same order: loss and ALL gradients must be bit for
+    bit those of the same engine with the overlap switched off, and so must the parameters after three optimiser steps."""
+    spec = O.ModelSpec(546, 500, 3, True, 'concat', 29)
+    B, T = 16, 150
+    feats, seq_len, labels, label_len = O.synth_batch(spec, B, T, seed=9, var_len=True, Lmin=5, Lmax=25)
+    p0 = O.flatten(O.init_params(spec, seed=1)).astype(np.float32)
+    e = make_engine(spec, lr=1e-3)
+    assert e.recurrence_mode == 'persistent'
+    if not e.wgrad_overlap:
+        e.close()
+        pytest.skip('NASR_WGRAD_OVERLAP=0')
+    out = {}
+    for mode in (True, False, True):
+        e.set_wgrad_overlap(mode)
+        assert e.wgrad_overlap == mode
+        e.set_params(p0)
+        e.set_adam_state(np.zeros_like(p0), np.zeros_like(p0), 0)
+        loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+        for _ in range(3):
+            e.train_step(feats, seq_len, labels, label_len)
+        res = (loss, nll, grads, e.get_params())
+        if mode in out:
+            prev = out[mode]
+        else:
+            prev = out.get(not mode)
+            out[mode] = res
+        if prev is not None:
+            assert res[0] == prev[0]
+            np.testing.assert_array_equal(res[1], prev[1])
+            np.testing.assert_array_equal(res[2], prev[2])
+            np.testing.assert_array_equal(res[3], prev[3])
+    assert e.persist_stats() == (0, 0)
+    e.close()
