@@ -28,6 +28,9 @@
 #ifndef WIDE_PF
 #define WIDE_PF 2        // k-tiles of A fragments read ahead of the MFMAs (tools/widebench A/B: 1, 2, 3)
 #endif
+#ifndef NASR_WIDE_EPOCH
+#define NASR_WIDE_EPOCH 1   // forward: the h all-gather is validated by epoch bits in the payload (0: flag, then payload)
+#endif
 #ifndef NASR_WSTAMP
 #define NASR_WSTAMP 0   // 1: s_memtime deltas per phase -> WideCtl::stamps (tools/widebench)
 #endif
@@ -160,6 +163,8 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
   extern __shared__ __attribute__((aligned(16))) u32x4 wlds[];
   using L = WideLds<MT>;
   constexpr int ROWS = 16 * MT;
+  constexpr bool EP = NASR_WIDE_EPOCH != 0;
+  constexpr int NCW = (8 * ROWS + 63) / 64;      // waves with cell threads
   u32x4* Alds = wlds + L::A;
   f32x4* Plds = reinterpret_cast<f32x4*>(wlds + L::P);
   _Float16* hp = reinterpret_cast<_Float16*>(wlds + L::HP);
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
   float osc[2];
 #pragma unroll
   for (int h2 = 0; h2 < 2; ++h2)
-    osc[h2] = cinv[4 * (KS * w + 8 * nb + 4 * h2 + ((lane & 15) >> 2)) + (lane & 3)] * (1.f / 16384.f);
+    osc[h2] = cinv[4 * (KS * w + 8 * nb + 4 * h2 + ((lane & 15) >> 2)) + (lane & 3)] * (EP ? 0.5f : 1.f / 16384.f);
 
   gu32* hflag = (gu32*)(ctl->hflag + x * 32);
 
@@ -225,11 +230,60 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
 
     if (s > 0) {
       // 1. h_{s-1} of this XCD's row slice: wave w fetches k-tile w = the 8 units of producers 4w .. 4w+3
+      const u32x4* src = hx + ((size_t)(((s - 1) & 1) * 8 + x) * 32 + 4 * w + (lane >> 4)) * 2 * ROWS + (lane & 15);
+      u32x4 v[MT][2];
+      if constexpr (EP) {
+        // ONE round trip, as in lstm_persist.hip: every half of the two planes carries the epoch of this use of the buffer in
+        // bit 14 (plane 0 = fp16(2h), plane 1 = fp16((2h - plane 0) * 2^10): both stay below 2, their exponent fields below
+        // 16), so the loads themselves say whether the four producers have published; a lane with a stale granule loads
+        // again.  Waves without cell threads first wait (in LDS) until this workgroup's own cell waves have published.
+        ok = !(s == gm.inject && me == 0);
+        if (ok) {
+          const unsigned want = (unsigned)s * (unsigned)NCW;
+          for (unsigned n = 0; n < (1u << 24) && (int)(*(volatile __attribute__((address_space(3))) unsigned*)(info + 3) - want) < 0; ++n)
+            __builtin_amdgcn_s_sleep(1);
+        }
+        WMARK(1);
+        if (ok) {
+          const unsigned em = ((((unsigned)(s - 1) >> 1) + 1u) & 1u) ? 0x40004000u : 0u;
+          bool need = true;
+          ok = false;
+          for (unsigned n = 0; n < WIDE_SPIN; ++n) {
+            if (need) {
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) v[m][p] = ld16_sc1(src + p * ROWS + 16 * m);
+            }
+            unsigned bad = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int p = 0; p < 2; ++p) {
+                wait_vm0(v[m][p]);
+                const u32x4 t = v[m][p];
+                bad |= (t.x ^ em) | (t.y ^ em) | (t.z ^ em) | (t.w ^ em);
+              }
+            need = (bad & 0x40004000u) != 0;
+            if (!__any(need)) { ok = true; break; }
+          }
+        }
+        if (ok) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              u32x4 t = v[m][p];
+              t.x &= 0xBFFFBFFFu; t.y &= 0xBFFFBFFFu; t.z &= 0xBFFFBFFFu; t.w &= 0xBFFFBFFFu;
+              Alds[((w * MT + m) * 2 + p) * 64 + lane] = t;
+            }
+        } else {
+          info[2] = 1;
+        }
+      } else {
       ok = wpoll_ge(hflag + 4 * w + (lane & 3), lane < 4, (unsigned)s) && !(s == gm.inject && me == 0);
       WMARK(1);
       if (ok) {
-        const u32x4* src = hx + ((size_t)(((s - 1) & 1) * 8 + x) * 32 + 4 * w + (lane >> 4)) * 2 * ROWS + (lane & 15);
-        u32x4 v[MT][2];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -244,6 +298,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
           for (int p = 0; p < 2; ++p) Alds[((w * MT + m) * 2 + p) * 64 + lane] = v[m][p];
       } else {
         info[2] = 1;
+      }
       }
     }
     WMARK(2);
@@ -263,6 +318,7 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
         // both 16 x 16 tiles of this M tile together; the A fragments of k-tile kt+1 are read while kt multiplies (the
         // scheduling barriers keep the compiler from hoisting every read to the top, which costs 64 registers per M tile)
         f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 t0b = (f32x4){0.f, 0.f, 0.f, 0.f}, t1b = (f32x4){0.f, 0.f, 0.f, 0.f};   // EP: the plane-1 products (scale 2^11 instead of 2)
         // fragments of k-tiles kt+1 and kt+2 are in flight while kt multiplies (PF = prefetch distance)
         constexpr int PF = WIDE_PF;
         h8 q0[PF + 1], q1[PF + 1];
@@ -278,14 +334,23 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
             q1[(kt + PF) % (PF + 1)] = __builtin_bit_cast(h8, Alds[(((kt + PF) * MT + m) * 2 + 1) * 64 + lane]);
           }
           const h8 c0 = q0[kt % (PF + 1)], c1 = q1[kt % (PF + 1)];
-          t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][0][0], t0, 0, 0, 0);
-          t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][1][0], t1, 0, 0, 0);
+          if constexpr (EP) {
+            t0b = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][0][0], t0b, 0, 0, 0);
+            t1b = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][1][0], t1b, 0, 0, 0);
+          } else {
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][0][0], t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, ur[kt][1][0], t1, 0, 0, 0);
+          }
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][0][1], t0, 0, 0, 0);
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][1][1], t1, 0, 0, 0);
           t0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][0][0], t0, 0, 0, 0);
           t1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0, ur[kt][1][0], t1, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (EP) {
+          t0 = t0 + t0b * (1.f / 1024.f);
+          t1 = t1 + t1b * (1.f / 1024.f);
+        }
         t0 *= osc[0];
         t1 *= osc[1];
         if (w != x) {
@@ -370,11 +435,21 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
         c = c * act.z + act.x * act.y;
         h = wtanh(c) * act.w;
       }
-      const float hv = h * 16384.f;
+      // (EP: |2h| is kept below 2 - tanh and the sigmoid saturate to exactly 1 - so that plane 0's exponent field stays below 16;
+      //  the residual of that clamp, 2^-10, is exact in plane 1)
+      const float hv = EP ? fminf(fmaxf(h * 2.f, -1.9990234375f), 1.9990234375f) : h * 16384.f;
+      const float hres = (EP ? h * 2.f : hv) - 0.f;
       const _Float16 h1 = (_Float16)hv;
-      const _Float16 h2v = (_Float16)(hv - (float)h1);
-      hp[(0 * ROWS + cb) * 8 + ci] = h1;
-      hp[(1 * ROWS + cb) * 8 + ci] = h2v;
+      const _Float16 h2v = (_Float16)(EP ? (hres - (float)h1) * 1024.f : (hv - (float)h1));
+      if constexpr (EP) {
+        // bit 14 of every half = the epoch of this use of the buffer (uses alternate 1, 0, 1, ... from a cleared buffer)
+        const unsigned short eb = ((((unsigned)s >> 1) + 1u) & 1u) ? 0x4000u : 0u;
+        reinterpret_cast<unsigned short*>(hp)[(0 * ROWS + cb) * 8 + ci] = __builtin_bit_cast(unsigned short, h1) | eb;
+        reinterpret_cast<unsigned short*>(hp)[(1 * ROWS + cb) * 8 + ci] = __builtin_bit_cast(unsigned short, h2v) | eb;
+      } else {
+        hp[(0 * ROWS + cb) * 8 + ci] = h1;
+        hp[(1 * ROWS + cb) * 8 + ci] = h2v;
+      }
       __builtin_amdgcn_wave_barrier();
       // the row's 8 halfs were written by 8 consecutive lanes of this wave: LDS operations of one wave complete in order
       if (ci == 0) {
@@ -382,7 +457,13 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
         dst[0] = *reinterpret_cast<const u32x4*>(hp + (0 * ROWS + cb) * 8);     // plain stores: land in this XCD's L2
         dst[ROWS] = *reinterpret_cast<const u32x4*>(hp + (1 * ROWS + cb) * 8);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // acknowledged before the flag goes out
+      if constexpr (EP) {
+        // no acknowledgement to wait for and no flag: the granules validate themselves.  The workgroup's other waves learn
+        // from an LDS counter that this cell wave has published.
+        if (lane == 0) atomicAdd(info + 3, 1u);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // acknowledged before the flag goes out
+      }
       // per-frame results for the BPTT / the layer above
       if (rowok) {
         if (valid) {
@@ -396,9 +477,13 @@ __global__ __launch_bounds__(512, 1) void lstm_wide_fwd_kernel(
         }
       }
     }
-    __syncthreads();                                        // #3: every cell wave's h is acknowledged
-    WMARK(9);
-    if (tid == 0) hflag[nb] = (unsigned)s + 1u;
+    if constexpr (!EP) {
+      __syncthreads();                                      // #3: every cell wave's h is acknowledged
+      WMARK(9);
+      if (tid == 0) hflag[nb] = (unsigned)s + 1u;
+    } else {
+      WMARK(9);
+    }
     if (abort_word) { aborted = true; break; }
   }
   WSTAMP_FLUSH;
@@ -836,6 +921,7 @@ void launch_lstm_wide_fwd(const LstmDims& dm, int d, const void* Uw, const float
                           float* fault, float forget_bias, hipStream_t st) {
   (void)hipMemsetAsync(ctl, 0, sizeof(WideCtl), st);
   (void)hipMemsetAsync(part, 0xff, wide_part_bytes(dm.Bp), st);   // every inbox word = the sentinel
+  if (NASR_WIDE_EPOCH) (void)hipMemsetAsync(hx, 0, wide_hx_bytes(dm.Bp), st);   // the h buffers start from epoch 0
   WideGeom gm{dm.T, dm.Bp, dm.Hp, dm.D, d, -1, 0, fault};
   if (const char* e = test_hook("NASR_WIDE_FAULT")) gm.inject = atoi(e);
   const int MT = dm.Bp / 16;
