@@ -58,6 +58,7 @@ class HipNetwork(Network):
     # train() returns as soon as the step's loss and decode exist (after the forward pass + CTC), while the device runs the
     # backward pass, the exchange and Adam: the next step is enqueued behind it and the device never waits for the host.
     # A void step (rare: a persistent-recurrence abort on some rank) is noticed one call later and repeated then.
+    # False: train() additionally waits for the END of its step (and repeats it there if it was void) - same code path.
     async_step = True
 
     def __init__(self, config, fortraining=False):
@@ -225,39 +226,31 @@ class HipNetwork(Network):
         next batch inside the timed step with the device idle, train.py:23-26)."""
         self.global_step += 1
         n, mine = self._towers()
-        if self.async_step and len(mine) == 1:
+        if len(mine) == 1:
             f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, mine[0])
             batch = (mfccs, f, l, s, ll, n)
-            self._begun = ('async', (batch, self._enqueue_step(*batch)))
+            self._begun = ('one', (batch, self._enqueue_step(*batch)))
         else:
-            self._begun = ('sync', (mfccs, labels, seq_len, labels_len))
+            self._begun = ('sliced', (mfccs, labels, seq_len, labels_len))
 
     def finish_step(self, lazy=False):
         """Second half of train(): (loss, mean_ler) of the step begun last - available after its forward pass + CTC; the
-        device may still be in its backward pass when this returns.  lazy=True: mean_ler may come back as a handle with a
-        .result() (the beam search of the step's logits still runs on host threads) - for a caller like train_model, which
-        only needs the LERs when it logs; multi-process runs average such a window with mean_over_ranks()."""
+        device may still be in its backward pass when this returns (async_step = False: it has ended, and was repeated if it
+        was void).  lazy=True: mean_ler may come back as a handle with a .result() (the beam search of the step's logits
+        still runs on host threads) - for a caller like train_model, which only needs the LERs when it logs; multi-process
+        runs average such a window with mean_over_ranks()."""
         kind, batch = self._begun
         self._begun = None
-        if kind == 'async':
-            return self._finish_async(*batch, lazy=lazy)
-        return self._train_sync(*batch)
+        if kind == 'sliced':
+            return self._train_sliced(*batch)
+        out = self._finish_async(*batch, lazy=lazy)
+        if not self.async_step:
+            self._settle()
+        return out
 
     def mean_over_ranks(self, value):
         """Mean of a host float over the towers' processes (reduce_mean of tfnetwork.py:135-136); the value itself with one."""
         return self.coll.mean_scalars([value])[0] if self.coll.world > 1 else float(value)
-
-    def _train_sync(self, mfccs, labels, seq_len, labels_len):
-        self._settle()
-        for attempt in range(3):
-            out = self._train_once(mfccs, labels, seq_len, labels_len)
-            # a rank whose persistent recurrence gave up voids the step on EVERY rank (the fault word is all-reduced with
-            # the gradients and turns Adam into a no-op); that rank now runs the per-step kernels: do the step again
-            if out is not None and not self.engine.step_void():
-                return out
-            self.logger.warning('step %d was void (persistent recurrence aborted on some rank): repeating it'
-                                % self.global_step)
-        raise RuntimeError('training step %d stayed void after 3 attempts' % self.global_step)
 
     # ------------------------------------------------------------------ the fast path of train()
     def _enqueue_step(self, mfccs, f, l, s, ll, n):
@@ -402,74 +395,40 @@ class HipNetwork(Network):
             except Exception:                   # noqa: BLE001 - already committed or discarded
                 pass
 
-    def _train_once(self, mfccs, labels, seq_len, labels_len):
+    def _train_sliced(self, mfccs, labels, seq_len, labels_len):
+        """num_gpus towers time-sliced on the one GPU of a single process: each tower's shard in turn through the engine, the
+        gradients summed on the host (average_gradients, tfnetwork.py:72-86), one Adam step; a void tower (its persistent
+        recurrence gave up: the handle runs the per-step kernels from then on) repeats the whole step."""
         from .._lib import NasrError
+        self._settle()
         n, mine = self._towers()
-        losses, lers, gsum = [], [], None
-        reduced = False
-        for k in mine:
-            f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, k)
-            ticket = self._take_staged(mfccs) if len(mine) == 1 else None
-            if ticket is not None:
-                self.engine.commit_batch(ticket)
-            elif not (self._use_device_context() and
-                      self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
-                self.engine.upload_batch(f, s, l, ll)
-            self.engine.set_step_decode(True, logits=self.train_ler_decoder == 'beam')
-            self.engine.compute_grads()
-            if self.coll.world > 1 and self.bucketed_allreduce:
-                # enqueue the exchange NOW, before the host waits for the loss: bucket i goes out as soon as the backward
-                # pass has finished it, under the BPTT of the layers below
-                if self._grad_tensor is None:
-                    self._grad_tensor = self.engine.grad_tensor()
-                    self._reducer = self.coll.bucketed(self.engine, self._grad_tensor)
-                if self._reducer is not None:
-                    self._reducer.all_reduce()
-                    reduced = True
-            # One tower in this process: the optimiser step is enqueued BEFORE the host waits for the loss, so the GPU
-            # does not idle through the host's wake-up (Adam is a no-op on the device if the step turns out void)
-            early_adam = len(mine) == 1
-            if early_adam:
-                if self.coll.world > 1 and not reduced:
-                    if self._grad_tensor is None:
-                        self._grad_tensor = self.engine.grad_tensor()
-                    self.coll.all_reduce_sum_(self._grad_tensor)
-                self.engine.apply_adam(1.0 / n)
-            # Everything of this tower that reads the step's results sits inside the void handling: a rank whose
-            # persistent recurrence gave up must still reach every collective below (the other ranks are waiting in
-            # them); the step is repeated by train()
-            try:
-                loss = self.engine.get_loss()
-                hyps = None if self.train_ler_decoder == 'beam' else self.engine.get_decoded(len(s), f.shape[1])
-                ler = self._step_ler(hyps, f, l, s, ll, lazy=False)     # beam: from the step's own logits, no second pass
-            except NasrError as exc:
-                if not self._is_abort(exc):
-                    raise
-                if self.coll.world == 1:
-                    return None                 # single process: nothing else to keep in step, just repeat
-                loss, ler = float('nan'), float('nan')
-            losses.append(loss)
-            lers.append(ler)
-            if len(mine) > 1:
-                g = self.engine.get_grads().astype(np.float64)
+        for attempt in range(3):
+            losses, lers, gsum, void = [], [], None, False
+            for k in mine:
+                f, l, s, ll = take_shard(mfccs, labels, seq_len, labels_len, n, k)
+                if not (self._use_device_context() and
+                        self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
+                    self.engine.upload_batch(f, s, l, ll)
+                self.engine.set_step_decode(True, logits=self.train_ler_decoder == 'beam')
+                self.engine.compute_grads()
+                try:
+                    losses.append(self.engine.get_loss())
+                    hyps = None if self.train_ler_decoder == 'beam' else self.engine.get_decoded(len(s), f.shape[1])
+                    lers.append(self._step_ler(hyps, f, l, s, ll, lazy=False))
+                    g = self.engine.get_grads().astype(np.float64)
+                except NasrError as exc:
+                    if not self._is_abort(exc):
+                        raise
+                    void = True
+                    break
                 gsum = g if gsum is None else gsum + g
-        if len(mine) > 1:                       # towers time-sliced on one GPU: host-side sum
-            self.engine.set_grads((gsum / n).astype(np.float32))
-            self.engine.apply_adam(1.0)
-        elif early_adam:
-            pass                                # already enqueued
-        elif self.coll.world > 1:               # one tower per GPU: RCCL all-reduce of the flat buffer
-            if not reduced:
-                if self._grad_tensor is None:
-                    self._grad_tensor = self.engine.grad_tensor()
-                self.coll.all_reduce_sum_(self._grad_tensor)
-            self.engine.apply_adam(1.0 / n)
-        else:
-            self.engine.apply_adam(1.0)
-        loss, ler = float(np.mean(losses)), float(np.mean(lers))
-        if self.coll.world > 1:
-            loss, ler = self.coll.mean_scalars([loss, ler])
-        return np.float32(loss), np.float32(ler)
+            if not void:
+                self.engine.set_grads((gsum / n).astype(np.float32))
+                self.engine.apply_adam(1.0)
+                if not self.engine.step_void():
+                    return np.float32(np.mean(losses)), np.float32(np.mean(lers))
+            self.logger.warning('step %d was void (persistent recurrence aborted): repeating it' % self.global_step)
+        raise RuntimeError('training step %d stayed void after 3 attempts' % self.global_step)
 
     def validate(self, mfccs, labels, seq_len, labels_len):
         self._settle()
