@@ -245,6 +245,15 @@ int nasr_settle_step(nasr_handle h, int previous, int* void_out);
 int64_t nasr_step_token(nasr_handle h);
 int nasr_settle_token(nasr_handle h, int64_t token, int* void_out);
 int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the resident batch */
+/* Ragged batches.  DataSet.get_next_batch (dataset.py:75-77) pads every utterance to the longest of its batch and
+ * tf.nn.(bidirectional_)dynamic_rnn (networks/bilstm_ctc_net.py:40-53) masks by sequence_length.  Here, when at least a
+ * tenth of a training batch's T x B frame rows are such padding, the operand passes and GEMMs of a plain (Bi)LSTM stack work
+ * on the frames t < seq_len[b] only (gathered on the way in, scattered on the way out); the recurrences still run T steps.
+ * Results are the uncompacted ones up to summation order.  On by default (NASR_COMPACT=0 in the environment: off);
+ * a change takes effect with the next batch uploaded or committed.  nasr_resident_rows: the rows those passes cover for
+ * the resident batch - sum(seq_len) when compacted, T x (B rounded up to 16) otherwise. */
+int nasr_set_row_compaction(nasr_handle h, int enabled);
+int nasr_resident_rows(nasr_handle h, int64_t* rows);
 
 /* TensorFlowNetwork.train fetches mean_ler with every step (networks/tfnetwork.py:188-189): with
  * step-decode enabled nasr_compute_grads / nasr_loss also run the greedy decoder on the step's logits

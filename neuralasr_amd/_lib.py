@@ -31,7 +31,7 @@ SYMBOLS = [
     'nasr_discard_batch', 'nasr_set_bucket_defer', 'nasr_comm_unique_id', 'nasr_comm_init', 'nasr_comm_size',
     'nasr_comm_allreduce_grads', 'nasr_comm_mean', 'nasr_comm_destroy', 'nasr_get_step_results', 'nasr_settle_step',
     'nasr_step_token', 'nasr_settle_token', 'nasr_diag_bucket_traffic', 'nasr_get_step_logits',
-    'nasr_set_wgrad_overlap', 'nasr_get_wgrad_overlap',
+    'nasr_set_wgrad_overlap', 'nasr_get_wgrad_overlap', 'nasr_set_row_compaction', 'nasr_resident_rows',
 ]
 
 
@@ -113,6 +113,8 @@ def load():
         'nasr_ctc_beam_search': (c_int, [fp, ip, c_int, c_int, c_int, c_int, c_int, ip, ip, fp]),
         'nasr_get_loss': (c_int, [H, fp]),
         'nasr_resident_frames': (c_int, [H, POINTER(c_int64)]),
+        'nasr_resident_rows': (c_int, [H, POINTER(c_int64)]),
+        'nasr_set_row_compaction': (c_int, [H, c_int]),
         'nasr_set_profiling': (c_int, [H, c_int]),
         'nasr_get_phase_times': (c_int, [H, POINTER(PhaseTimes)]),
         'nasr_set_graph_mode': (c_int, [H, c_int]),

@@ -59,6 +59,7 @@ struct GemmTPHParams {
   // K slices x batch) and the i-th workgroup of an XCD takes tile (r fastest, then c, then z) of its own sub-grid:
   // the workgroups that run together on one XCD share their operand tiles through that XCD's L2.
   int swz, gx, gy, gz, pr, pc, pz, sr, sc, sz;    // sr x sc x sz: sub-grid of one XCD
+  const int* c_map;        // (or NULL) output row m is written to row c_map[m] of C (-1: not at all): compacted rows scattered back
 };
 
 __device__ __forceinline__ void emit_h2(const float (&x)[8], float s, unsigned char* dst) {
@@ -270,11 +271,15 @@ void launch_fill(float* p, float v, int n, hipStream_t st) {
 // One pass over src [rows][K]: tpN = planes of src scaled per src row (row_scale, or the constant rs when NULL), tpT =
 // planes of its transpose scaled per src column (col_scale / cs); either may be NULL.  colpart as in gemm_tp.hip's fused
 // pass: [gridDim.y][K] partial column sums of the UNSCALED src.
+// rowmap (or NULL): logical row i of this pass is physical row rowmap[i] of src (-1: a zero row) - the COMPACTED rows of a ragged
+// batch (nasr_batch.hip: only the frames t < seq_len[b], time-major); rowmap2 replaces it for the column blocks from col2 on
+// (the two directions of a layer's output shifted by one frame in opposite directions: the recurrent weight gradient).
 __global__ __launch_bounds__(256) void tph_split2_kernel(const float* __restrict__ src, unsigned char* __restrict__ tpN,
                                                          unsigned char* __restrict__ tpT, int rows, int K, int ld,
                                                          const float* __restrict__ row_scale, float rs,
                                                          const float* __restrict__ col_scale, float cs,
-                                                         float* __restrict__ colpart) {
+                                                         float* __restrict__ colpart, const int* __restrict__ rowmap,
+                                                         const int* __restrict__ rowmap2, int col2) {
   __shared__ float tile[64][65];
   __shared__ float csum[4][64];
   const int t = threadIdx.x;
@@ -286,12 +291,16 @@ __global__ __launch_bounds__(256) void tph_split2_kernel(const float* __restrict
     const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 + r < rows) {
-      const float* s = src + (size_t)(r0 + r) * ld + c0 + c;
-      if (c0 + c + 4 <= K) v = *reinterpret_cast<const float4*>(s);
-      else {
-        if (c0 + c < K) v.x = s[0];
-        if (c0 + c + 1 < K) v.y = s[1];
-        if (c0 + c + 2 < K) v.z = s[2];
+      const int* mp = (rowmap2 && c0 >= col2) ? rowmap2 : rowmap;
+      const int pr = mp ? mp[r0 + r] : r0 + r;
+      if (pr >= 0) {
+        const float* s = src + (size_t)pr * ld + c0 + c;
+        if (c0 + c + 4 <= K) v = *reinterpret_cast<const float4*>(s);
+        else {
+          if (c0 + c < K) v.x = s[0];
+          if (c0 + c + 1 < K) v.y = s[1];
+          if (c0 + c + 2 < K) v.z = s[2];
+        }
       }
     }
     tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
@@ -344,10 +353,21 @@ int gemm_tp_tile_rows(int M) {
 size_t tph_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * ((K + 15) / 16) * 2 * HTB; }
 
 void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
-                       const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st) {
+                       const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st,
+                       const int* rowmap, const int* rowmap2, int col2) {
   dim3 grid((K + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(tph_split2_kernel, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld, row_scale, rs, col_scale, cs,
-                     colpart);
+                     colpart, rowmap, rowmap2, col2);
+}
+
+// dst[i] = map[i] >= 0 ? src[map[i]] : fill  (row scales of a compacted operand)
+__global__ __launch_bounds__(256) void gather_rows_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                          const int* __restrict__ map, int n, float fill) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : fill;
+}
+void launch_gather_rows(float* dst, const float* src, const int* map, int n, float fill, hipStream_t st) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, map, n, fill);
 }
 
 // ------------------------------------------------------------------ the GEMM
@@ -472,8 +492,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void gemm_tph_kern
         const int row = m0 + wm * (32 * TMW) + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= p.M) continue;
         const float v = acc[mi][ni][r] * (ainv[row] * sb);        // powers of two: exact
-        if (p.split_k > 1) p.slabs[((size_t)bzz * p.M + row) * p.N + col] = v;
-        else p.C[(size_t)bz * p.c_bstride + (size_t)row * p.ldc + col] = v + bv;
+        if (p.split_k > 1) {
+          p.slabs[((size_t)bzz * p.M + row) * p.N + col] = v;
+        } else {
+          const int orow = p.c_map ? p.c_map[row] : row;
+          if (orow >= 0) p.C[(size_t)bz * p.c_bstride + (size_t)orow * p.ldc + col] = v + bv;
+        }
       }
     }
 }
@@ -529,6 +553,7 @@ void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st) {
   p.ainv_bstride = (long long)g.ainv_bstride; p.binv_bstride = (long long)g.binv_bstride;
   p.a_kb_shift1 = g.a_kshift1 / 16;
   dim3 grid((g.N + tn - 1) / tn, (g.M + tm - 1) / tm, p.split_k * p.nbatch);
+  p.c_map = g.c_map;
   p.swz = 0;
   p.gx = (int)grid.x; p.gy = (int)grid.y; p.gz = (int)grid.z;
   p.pr = p.pc = p.pz = 1; p.sr = p.gy; p.sc = p.gx; p.sz = p.gz;
@@ -556,7 +581,10 @@ void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st) {
   else if (g.side) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3>), grid, dim3(192), TPH_LDS_SIDE, st, p);
   else if (tm == 192) hipLaunchKernelGGL((gemm_tph_kernel<3, 2, 4>), grid, dim3(512), TPH_LDS, st, p);
   else hipLaunchKernelGGL((gemm_tph_kernel<4, 2, 4>), grid, dim3(512), TPH_LDS, st, p);
-  if (p.split_k > 1) launch_reduce_slabs(g.slabs, p.split_k, (int64_t)p.nbatch * g.M * g.N, g.C, st);
+  if (p.split_k > 1) {
+    if (g.c_map) launch_reduce_slabs_rows(g.slabs, p.split_k, g.M, g.N, g.ldc, g.c_map, g.C, st);
+    else launch_reduce_slabs(g.slabs, p.split_k, (int64_t)p.nbatch * g.M * g.N, g.C, st);
+  }
 }
 
 }  // namespace nasr

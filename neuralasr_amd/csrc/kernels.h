@@ -60,8 +60,11 @@ void launch_fill(float* p, float v, int n, hipStream_t st);
 // one pass over src [rows][K]: tpN = planes of src (scale per src row: row_scale[] or the constant rs), tpT = planes of its
 // transpose (scale per src column: col_scale[] or cs); either may be NULL; colpart (or NULL): tp_split2_parts(rows) x K
 // partial column sums of src, finished by launch_colsum_parts
+// rowmap (or NULL): logical row i = physical row rowmap[i] of src (-1: zero row); rowmap2: the same for the columns from col2 on
 void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT, int rows, int K, int ld,
-                       const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st);
+                       const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st,
+                       const int* rowmap = nullptr, const int* rowmap2 = nullptr, int col2 = 0);
+void launch_gather_rows(float* dst, const float* src, const int* map, int n, float fill, hipStream_t st);
 struct GemmTPHDesc {
   const unsigned char* A;   // TPH of [>= M rows][K_A], starting at the first row block used
   const unsigned char* B;   // TPH of [>= N rows][K_B]
@@ -84,6 +87,7 @@ struct GemmTPHDesc {
   int64_t c_bstride, ainv_bstride, binv_bstride;
   int a_kshift1;
   bool side;                // the 3-wave 128 x 192 instantiation that fits beside a persistent-recurrence workgroup
+  const int* c_map;         // (or NULL) output row m goes to row c_map[m] of C (-1: dropped); nbatch == 1 only
 };
 hipError_t gemm_tph_prepare();
 int gemm_tph_pick_split(int M, int N, int K, int nbatch = 1, bool side = false);
@@ -215,6 +219,7 @@ void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, AdamDe
 void launch_colsum(const float* M, int R, int N, int ld, float* out, float* ws, hipStream_t st);
 void launch_colsum_parts(const float* part, int nparts, int N, float* out, hipStream_t st);   // out[n] = sum_k part[k][n]
 void launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, hipStream_t st);
+void launch_reduce_slabs_rows(const float* slabs, int S, int M, int N, int ldc, const int* map, float* out, hipStream_t st);
 // diagnostics: nblocks x 256 threads sweep buf[0..n) `passes` times with 16-byte loads / stores, data unchanged
 void launch_ring_standin(float* buf, int64_t n, int nblocks, int passes, hipStream_t st);
 

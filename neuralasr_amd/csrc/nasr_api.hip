@@ -99,6 +99,10 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   }
   if (build_layout(h) != NASR_OK) return bail(NASR_ERR_ARG, t_err);
   {
+    const char* ec = getenv("NASR_COMPACT");
+    h->compactable = h->ndense == 0 && !(ec && ec[0] == '0');
+  }
+  {
     h->sc_wr.resize(h->L); h->sc_wc.resize(h->L);
     h->sc_dr.resize(h->ndense); h->sc_dc.resize(h->ndense); h->sc_yr.resize(h->ndense); h->sc_yc.resize(h->ndense);
     {
@@ -325,6 +329,7 @@ int nasr_destroy(nasr_handle h) {
   if (h->perr) (void)hipHostFree(h->perr);
   for (DevBuf* b : {&h->XTP, &h->X0TTP, &h->GTP, &h->GTTP, &h->scws, &h->GTTP2, &h->csws2, &h->slabs2}) b->release();
   h->sc_gc2.release();
+  h->sc_cr.release(); h->sc_cx.release(); h->OTS.release();
   if (h->wst) { (void)hipStreamSynchronize(h->wst); (void)hipStreamDestroy(h->wst); }
   if (h->ev_dx) (void)hipEventDestroy(h->ev_dx);
   for (hipEvent_t e : h->ev_wg) if (e) (void)hipEventDestroy(e);
@@ -693,6 +698,19 @@ int nasr_settle_token(nasr_handle h, int64_t token, int* void_out) {
 int nasr_resident_frames(nasr_handle h, int64_t* frames) {
   if (!h || !frames) return NASR_ERR_ARG;
   *frames = h->resident ? h->frames : 0;
+  return NASR_OK;
+}
+
+int nasr_set_row_compaction(nasr_handle h, int enabled) {
+  if (!h) return NASR_ERR_ARG;
+  // what the resident batch's plane buffers hold depends on it: takes effect with the next uploaded / committed batch
+  h->compactable = enabled && h->ndense == 0;
+  return NASR_OK;
+}
+
+int nasr_resident_rows(nasr_handle h, int64_t* rows) {
+  if (!h || !rows) return NASR_ERR_ARG;
+  *rows = !h->resident ? 0 : h->cmp_rows ? h->cmp_rows : (int64_t)h->T * h->Bp;
   return NASR_OK;
 }
 

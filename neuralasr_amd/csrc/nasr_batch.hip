@@ -51,6 +51,10 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
       }
       ok &= h->sc_x0r.ensure(R) && h->sc_x0c.ensure((size_t)h->Fp);
       ok &= h->sc_gr.ensure(R) && h->sc_gc.ensure((size_t)wmax);
+      if (h->compactable) {
+        ok &= h->sc_cr.ensure(R + 64) && h->sc_cx.ensure(R + 64);
+        ok &= h->OTS.ensure((h->wg_overlap ? 2 : 1) * tph_bytes(D * Hp, (int)R), &grew);
+      }
       for (int i = 0; i < h->ndense; ++i) ok &= h->sc_yr[i].ensure(R) && h->sc_yc[i].ensure((size_t)h->dWp[i]);
       bool g2 = false;
       ok &= h->scws.ensure(tph_scale_ws_floats((int)R, std::max(ipmax, wmax)) * 4, &g2);
@@ -173,7 +177,16 @@ int slot_fill(nasr_ctx* h, BatchSlot* s, const float* feats, const int32_t* seq_
   s->o_cstart = s->o_labels + (size_t)B * Lm;
   s->o_cpos = s->o_cstart + (labels ? (size_t)B * (C + 1) : 0);
   s->o_rowmap = s->o_cpos + (size_t)B * Lm;
-  const size_t nmeta = s->o_rowmap + (sr ? (size_t)Tp * Bp : 0);
+  // compacted rows: worth it when at least a tenth of the T x Bp rows are padding (and only for training batches)
+  int64_t rv = 0;
+  for (int b = 0; b < B; ++b) rv += seq_len[b];
+  s->cmp = h->compactable && labels && rv * 10 <= (int64_t)T * Bp * 9;
+  s->Rv = s->cmp ? (int)rv : 0;
+  s->Rvp = s->cmp ? rup((int)rv, 64) : 0;
+  s->o_vrow = s->o_rowmap + (sr ? (size_t)Tp * Bp : 0);
+  s->o_vprev = s->o_vrow + s->Rvp;
+  s->o_vnext = s->o_vprev + s->Rvp;
+  const size_t nmeta = s->o_vnext + s->Rvp;
   const size_t nfeat = centre ? (size_t)B * T * ncep + B : (size_t)B * T * h->F;
   bool grew = false;
   if (!s->dmeta.ensure(nmeta * 4, &grew) || !s->dfeats.ensure(nfeat * 4, &grew) ||
@@ -216,6 +229,19 @@ int slot_fill(nasr_ctx* h, BatchSlot* s, const float* feats, const int32_t* seq_
         const int b = (int)(rem / T), t = (int)(rem % T);
         map[(size_t)tp * Bp + bq] = (t * Bp + b) * 2 + d;
       }
+  }
+  if (s->cmp) {
+    int32_t *vr = m + s->o_vrow, *vp = m + s->o_vprev, *vn = m + s->o_vnext;
+    int i = 0;
+    for (int t = 0; t < T; ++t)
+      for (int b = 0; b < B; ++b)
+        if (seq_len[b] > t) {
+          vr[i] = t * Bp + b;
+          vp[i] = t > 0 ? (t - 1) * Bp + b : -1;
+          vn[i] = t + 1 < seq_len[b] ? (t + 1) * Bp + b : -1;
+          ++i;
+        }
+    for (; i < s->Rvp; ++i) vr[i] = vp[i] = vn[i] = -1;
   }
   if (centre) {
     const size_t nc = (size_t)B * T * ncep;
@@ -266,6 +292,10 @@ int slot_commit(nasr_ctx* h, BatchSlot* s) {
   HIPCHK(h, hipMemcpyAsync(h->seqbuf.p, md + s->o_seq, (size_t)Bp * 4, hipMemcpyDeviceToDevice, h->st));
   h->seq_p = h->seqbuf.as<int32_t>(); h->lablen_p = md + s->o_lablen; h->labels_p = md + s->o_labels;
   h->cstart_p = md + s->o_cstart; h->cpos_p = md + s->o_cpos; h->rowmap_p = md + s->o_rowmap;
+  const bool cmp = s->cmp && h->compactable;      // (staged with it on, switched off since: the slot's row lists go unused)
+  h->cmp_rows = cmp ? s->Rv : 0;
+  h->cmp_rows_p = cmp ? s->Rvp : 0;
+  h->vrow_p = md + s->o_vrow; h->vprev_p = md + s->o_vprev; h->vnext_p = md + s->o_vnext;
   h->ev_used = 0;
   h->spans.clear();
   if (h->profiling) {
@@ -285,9 +315,12 @@ int slot_commit(nasr_ctx* h, BatchSlot* s) {
     else
       launch_pack_feats(s->dfeats.as<float>(), h->X0.as<float>(), B, Bp, T, h->F, h->Fp, h->st);
     pl_scales(h, h->X0.as<float>(), T * Bp, h->Fp, h->Fp, &h->sc_x0r, &h->sc_x0c, h->st);
+    if (h->cmp_rows)    // the feature rows' scales in the compacted order (layer 0's input GEMM)
+      launch_gather_rows(h->sc_cx.sp(), h->sc_x0r.sp(), h->vrow_p, h->cmp_rows_p, 1.f, h->st),
+      launch_gather_rows(h->sc_cx.ip(), h->sc_x0r.ip(), h->vrow_p, h->cmp_rows_p, 1.f, h->st);
     if (s->has_labels && h->npre == 0)   // layer-0 input with the frame index as contraction index, for dWx = X^T dG
-      pl_split(h->X0.as<float>(), nullptr, h->X0TTP.as<unsigned char>(), T * Bp, h->Fp, h->Fp, nullptr, h->sc_x0c.sp(),
-               nullptr, h->st);
+      launch_tph_split2(h->X0.as<float>(), nullptr, h->X0TTP.as<unsigned char>(), h->cmp_rows ? h->cmp_rows : T * Bp, h->Fp, h->Fp,
+                        nullptr, 1.f, h->sc_x0c.sp(), 1.f, nullptr, h->st, h->cmp_rows ? h->vrow_p : nullptr);
     HIPCHK(h, hipGetLastError());
   }
   h->resident = true;

@@ -104,6 +104,9 @@ struct BatchSlot {
   bool has_labels = false, centre = false;
   int64_t frames = 0;
   size_t o_seq = 0, o_lablen = 0, o_labels = 0, o_cstart = 0, o_cpos = 0, o_rowmap = 0;   // int offsets into meta
+  size_t o_vrow = 0, o_vprev = 0, o_vnext = 0;   // compacted rows of a ragged batch (Rv of them, padded to Rvp with -1), or unused
+  int Rv = 0, Rvp = 0;
+  bool cmp = false;
   int32_t* meta_d() const { return dmeta.as<int32_t>(); }
 };
 
@@ -254,6 +257,16 @@ struct nasr_ctx {
   // device arrays of the resident batch (inside cur->dmeta / cur->dfeats)
   int32_t *seq_p = nullptr, *lablen_p = nullptr, *labels_p = nullptr, *cstart_p = nullptr, *cpos_p = nullptr,
           *rowmap_p = nullptr;
+  // Ragged batches (dataset.py:75-77 pads every utterance to the batch maximum): when at least a tenth of the T x Bp frame rows
+  // are padding, the plane passes and GEMMs of a plain (Bi)LSTM stack work on the COMPACTED rows - only the frames t < seq_len[b],
+  // time-major - and scatter their results back (split passes gather by vrow, GEMM epilogues scatter by it; vprev / vnext =
+  // the row of the frame before / after each compacted row, -1 at an utterance's first / last frame: the h_{t-1} operand of
+  // the recurrent weight gradient).  cmp_rows = Rv (0: no compaction for the resident batch).  NASR_COMPACT=0 turns it off.
+  bool compactable = false;
+  int cmp_rows = 0, cmp_rows_p = 0;
+  int32_t *vrow_p = nullptr, *vprev_p = nullptr, *vnext_p = nullptr;
+  SV sc_cr, sc_cx;                           // row scales gathered to the compacted order: dG rows / feature rows
+  DevBuf OTS;                                // planes of shift(out[l])^T over the compacted rows (recurrent weight gradient)
 
   // Weight gradients under the BPTT of the layer below (persistent mode, Hp = 512, L > 1; NASR_WGRAD_OVERLAP=0 turns it off): weight_grads(l)
   // runs on a low-priority side stream in the 3-wave GEMM instantiation that fits on a CU beside a persistent workgroup,

@@ -122,40 +122,56 @@ void dg_scales(nasr_ctx* h, int l, int R, bool rows, hipStream_t st) {
   }
 }
 
-// gates_l = X_l * Wx_l + bias_l over all R rows
+// gates_l = X_l * Wx_l + bias_l over all R rows - or, for a ragged batch (h->cmp_rows, nasr_ctx.h), over its frames only:
+// the split pass gathers them, the epilogue scatters the result rows back (padding rows of gates_l keep what they had; the
+// recurrence kernels select by t < seq_len[b] and never use them)
 void gemm_xproj(nasr_ctx* h, int l, int R, hipStream_t st) {
   const int D = h->D, N4 = h->N4, Ip = h->Ip[l];
-  const ActScale as = lstm_in_scale(h, l);
+  const int rows = h->cmp_rows ? h->cmp_rows : R;
+  const int* vm = h->cmp_rows ? h->vrow_p : nullptr;
+  ActScale as = lstm_in_scale(h, l);
+  if (vm && l == 0) { as.rs = h->sc_cx.sp(); as.rinv = h->sc_cx.ip(); }   // the feature rows' scales in the compacted order
   // a training step wants the layer below's output a second time, with the frame index as contraction index (its own
   // recurrent weight gradient and this layer's input weight gradient): both plane sets in this one pass over it
   const bool both = l > 0 && h->cur && h->cur->has_labels;
-  pl_split(lstm_input(h, l), h->XTP.as<unsigned char>(), both ? h->OTT[l - 1].as<unsigned char>() : nullptr, R, Ip, Ip, as.rs,
-           both ? as.cs : nullptr, nullptr, st);
+  launch_tph_split2(lstm_input(h, l), h->XTP.as<unsigned char>(), both ? h->OTT[l - 1].as<unsigned char>() : nullptr, rows, Ip, Ip,
+                    as.rs, 1.f, both ? as.cs : nullptr, 1.f, nullptr, st, vm);
   if (l > 0) h->ott_valid[l - 1] = both;
   GemmTPHDesc g{};
   g.A = h->XTP.as<unsigned char>(); g.B = h->WfTP + h->off_wftp[l]; g.C = h->gates[l].as<float>();
-  g.M = R; g.N = D * N4; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * N4;
+  g.M = rows; g.N = D * N4; g.K = Ip; g.nkbA = (Ip + 15) / 16; g.nkbB = g.nkbA; g.ldc = D * N4;
   g.bias = h->P + h->off_bias[l]; g.split_k = 1;
+  g.c_map = vm;
   pl_gemm(g, as.rinv, h->sc_wc[l].ip(), st);
 }
 
 // dOut_{l-1} = dG_l * Wx_l^T : the gradient wrt layer l's input = the layer below's output.  weight_grads(l) follows:
 // dG is split ONCE into both plane sets (frame-row scales for this product, gate-column scales for the weight gradients)
-// and its 64-row partial column sums (the bias gradient).
+// and its 64-row partial column sums (the bias gradient).  (Ragged batch: over the compacted rows, as gemm_xproj.)
 void gemm_dx(nasr_ctx* h, int l, int R, hipStream_t st) {
   const int D = h->D, N4 = h->N4;
+  const int rows = h->cmp_rows ? h->cmp_rows : R;
+  const int* vm = h->cmp_rows ? h->vrow_p : nullptr;
   const float* A = dg_of(h, l);
   float* C = l > 0 ? dout_of(h, l - 1) : h->dYbuf[h->npre - 1].as<float>();
   dg_scales(h, l, R, true, st);
-  pl_split(A, h->GTP.as<unsigned char>(), gttp_of(h, l), R, D * N4, D * N4, h->sc_gr.sp(), gc_of(h, l).sp(), csws_of(h, l), st);
+  const float *rs = h->sc_gr.sp(), *rinv = h->sc_gr.ip();
+  if (vm) {
+    launch_gather_rows(h->sc_cr.sp(), h->sc_gr.sp(), vm, h->cmp_rows_p, 1.f, st);
+    launch_gather_rows(h->sc_cr.ip(), h->sc_gr.ip(), vm, h->cmp_rows_p, 1.f, st);
+    rs = h->sc_cr.sp(); rinv = h->sc_cr.ip();
+  }
+  launch_tph_split2(A, h->GTP.as<unsigned char>(), gttp_of(h, l), rows, D * N4, D * N4, rs, 1.f, gc_of(h, l).sp(), 1.f,
+                    csws_of(h, l), st, vm);
   h->gttp_layer = l;   // weight_grads(l): transposed planes and column-sum partials of dG are there
   GemmTPHDesc g{};
   g.A = h->GTP.as<unsigned char>(); g.B = h->WbTP + h->off_wbtp[l]; g.C = C;
-  g.M = R; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = h->Ip[l];
+  g.M = rows; g.N = h->Ip[l]; g.K = D * N4; g.nkbA = (D * N4 + 15) / 16; g.nkbB = g.nkbA; g.ldc = h->Ip[l];
   g.split_k = gemm_tph_pick_split(g.M, g.N, g.K);
   g.slabs = ensure_slabs(h, g.split_k, g.M, g.N);
   if (g.split_k > 1 && !g.slabs) g.split_k = 1;
-  pl_gemm(g, h->sc_gr.ip(), h->sc_wr[l].ip(), st);
+  g.c_map = vm;
+  pl_gemm(g, rinv, h->sc_wr[l].ip(), st);
 }
 
 // ---- dense stages (networks/deepspeech.py:43-68,106-113) -----------------------------------------------------
@@ -326,7 +342,10 @@ int weight_grads(nasr_ctx* h, int l, hipStream_t ws, bool side) {
     bool grew = false;
     return slab_buf.ensure((size_t)split * M * N * 4, &grew) ? slab_buf.as<float>() : nullptr;
   };
-  const int nkb = (R + 15) / 16;
+  // a ragged batch contracts over its frames only (h->cmp_rows, nasr_ctx.h): every operand below is then gathered by vrow
+  const int rows = h->cmp_rows ? h->cmp_rows : R;
+  const int* vm = h->cmp_rows ? h->vrow_p : nullptr;
+  const int nkb = (rows + 15) / 16;
   // The side instantiation splits K exactly as the main one would: every output element then sums the same k-blocks in
   // the same order whatever the tile shape - the gradients are bitwise those of the serial order.  (NASR_SIDE_SPLIT=own:
   // the split its own cost model picks, for the A/B logs.)
@@ -336,38 +355,47 @@ int weight_grads(nasr_ctx* h, int l, hipStream_t ws, bool side) {
   // one pass over dG: its transposed planes + 64-row partial column sums (already there when gemm_dx(l) ran)
   if (h->gttp_layer != l) {
     dg_scales(h, l, R, false, ws);
-    pl_split(dG, nullptr, GT, R, D * N4, D * N4, nullptr, gc.sp(), cs_part, ws);
+    launch_tph_split2(dG, nullptr, GT, rows, D * N4, D * N4, nullptr, 1.f, gc.sp(), 1.f, cs_part, ws, vm);
   }
   h->gttp_layer = -1;
   const ActScale ao = act_out(h), ai = lstm_in_scale(h, l);
-  for (int m = std::max(l - 1, 0); m <= l; ++m)     // out[l] (recurrent weight gradient), out[l-1] (input weight gradient)
+  // out[l-1] (input weight gradient) and out[l] (recurrent weight gradient) with the frame index as contraction index, where
+  // the forward pass has not left them (gemm_xproj).  Compacted rows: out[l] is wanted SHIFTED by one frame, which is no
+  // constant row offset there - its planes are built here from the rows vprev (forward direction's columns) / vnext
+  // (backward direction's), and the plain transposed planes of out[l] are not needed at all.
+  for (int m = std::max(l - 1, 0); m <= (vm ? l - 1 : l); ++m)
     if (!h->ott_valid[m]) {
-      pl_split(h->outb[m].as<float>(), nullptr, h->OTT[m].as<unsigned char>(), R, D * Hp, D * Hp, nullptr, ao.cs, nullptr, ws);
+      launch_tph_split2(h->outb[m].as<float>(), nullptr, h->OTT[m].as<unsigned char>(), rows, D * Hp, D * Hp, nullptr, 1.f, ao.cs, 1.f,
+                        nullptr, ws, vm);
       h->ott_valid[m] = 1;
     }
+  unsigned char* OS = h->OTS.as<unsigned char>() + (wg_alt(h, l) ? tph_bytes(D * Hp, R) : 0);
+  if (vm)
+    launch_tph_split2(h->outb[l].as<float>(), nullptr, OS, rows, D * Hp, D * Hp, nullptr, 1.f, ao.cs, 1.f, nullptr, ws, h->vprev_p,
+                      D == 2 ? h->vnext_p : nullptr, Hp);
   if (l == 0 && h->npre)
     pl_split(lstm_input(h, l), nullptr, h->X0TTP.as<unsigned char>(), R, h->Ip[0], h->Ip[0], nullptr, ai.cs, nullptr, ws);
   {  // dWx = X^T dG
     GemmTPHDesc g{};
     g.A = l == 0 ? h->X0TTP.as<unsigned char>() : h->OTT[l - 1].as<unsigned char>();
     g.B = GT; g.C = h->G + h->off_wx[l];
-    g.M = h->Ip[l]; g.N = D * N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
+    g.M = h->Ip[l]; g.N = D * N4; g.K = rows; g.nkbA = nkb; g.nkbB = nkb; g.ldc = D * N4;
     g.side = side;
     g.split_k = side_one ? 1 : gemm_tph_pick_split(g.M, g.N, g.K, 1, side_split);
     g.slabs = slabs_for(g.split_k, g.M, g.N);
     if (g.split_k > 1 && !g.slabs) return h->fail(NASR_ERR_HIP, "slab workspace allocation failed");
     pl_gemm(g, ai.cinv, gc.ip(), ws);
   }
-  launch_colsum_parts(cs_part, tp_split2_parts(R), D * N4, h->G + h->off_bias[l], ws);
+  launch_colsum_parts(cs_part, tp_split2_parts(rows), D * N4, h->G + h->off_bias[l], ws);
   {  // dU = shift(H)^T dG : h_prev of frame t is out[t-1] (fw) / out[t+1] (bw); both directions in one launch
     GemmTPHDesc g{};
-    g.A = h->OTT[l].as<unsigned char>(); g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
-    g.M = Hp; g.N = N4; g.K = R; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
-    g.a_kshift = -Bp;
+    g.A = vm ? OS : h->OTT[l].as<unsigned char>(); g.B = GT; g.C = h->G + h->off_u[(size_t)l * D];
+    g.M = Hp; g.N = N4; g.K = rows; g.nkbA = nkb; g.nkbB = nkb; g.ldc = N4;
+    g.a_kshift = vm ? 0 : -Bp;
     g.nbatch = D;
     g.a_bstride = (size_t)(Hp / 32) * pl_rb_bytes(nkb); g.b_bstride = (size_t)(N4 / 32) * pl_rb_bytes(nkb);
     g.c_bstride = (int64_t)Hp * N4;            // off_u[l*D + 1] - off_u[l*D] (build_layout)
-    g.a_kshift1 = Bp;
+    g.a_kshift1 = vm ? 0 : Bp;
     g.side = side;
     g.split_k = side_one ? 1 : gemm_tph_pick_split(g.M, g.N, g.K, D, side_split);
     g.slabs = slabs_for(g.split_k * D, g.M, g.N);
@@ -449,6 +477,9 @@ int backward(nasr_ctx* h) {
       HIPCHK(h, hipEventRecord(h->ev_bucket[h->bucket_of_layer[l + 1]], h->st));
     }
     PhaseScope ps(h, PH_WGRAD);
+    // layer l+2's side-stream weight gradients read the plane buffers this layer's passes are about to rewrite (they
+    // finished a BPTT launch ago: the wait costs nothing, it only makes the order formal)
+    if (int rc = wg_join(h, l + 2)) return rc;
     if (l > 0 || h->npre > 0) gemm_dx(h, l, R, h->st);   // critical path first
     // layer l's weight gradients feed nothing before Adam: with the overlap on they leave the main stream here and run
     // beside the persistent BPTT launch of layer l-1 (tfnetwork.py:120-128: the gradients are a set, nothing orders them)

@@ -132,6 +132,28 @@ void launch_reduce_slabs(const float* slabs, int S, int64_t n, float* out, hipSt
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, S, n, out);
 }
 
+// the same for a result whose rows are scattered: out[map[m] * ldc + n] = sum_s slabs[s][m][n] (rows with map[m] < 0 dropped)
+__global__ __launch_bounds__(256) void reduce_slabs_rows_kernel(const float* __restrict__ slabs, int S, int M, int N, int ldc,
+                                                                const int* __restrict__ map, float* __restrict__ out) {
+  const int64_t n4 = (int64_t)M * N / 4, per = (int64_t)M * N;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i * 4 / N), c = (int)(i * 4 % N);
+    const int orow = map[m];
+    if (orow < 0) continue;
+    float4 a = *reinterpret_cast<const float4*>(slabs + i * 4);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(slabs + s * per + i * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)orow * ldc + c) = a;
+  }
+}
+void launch_reduce_slabs_rows(const float* slabs, int S, int M, int N, int ldc, const int* map, float* out, hipStream_t st) {
+  int blocks = (int)(((int64_t)M * N / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(reduce_slabs_rows_kernel, dim3(blocks), dim3(256), 0, st, slabs, S, M, N, ldc, map, out);
+}
+
 // ---- diagnostics: a kernel shaped like a ring all-reduce step ---------------------------------------------------------
 // `nblocks` workgroups of 256 threads; each sweeps its slice of the buffer `passes` times with 16-byte loads and stores
 // (x * 1: the data keep their bits), i.e. it holds its CUs for as long as RCCL's ring kernels hold theirs and moves bytes

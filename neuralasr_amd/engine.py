@@ -363,6 +363,16 @@ class Engine:
         self._ck(self.lib.nasr_resident_frames(self.h, byref(n)))
         return n.value
 
+    def resident_rows(self):
+        """Rows the operand passes and GEMMs cover for the resident batch: sum(seq_len) when the ragged batch was compacted
+        (nasr.h: nasr_set_row_compaction), T x padded B otherwise."""
+        n = c_int64()
+        self._ck(self.lib.nasr_resident_rows(self.h, byref(n)))
+        return n.value
+
+    def set_row_compaction(self, on):
+        self._ck(self.lib.nasr_set_row_compaction(self.h, int(bool(on))))
+
     def grad_device_ptr(self):
         return int(self.lib.nasr_grad_device_ptr(self.h)), int(self.lib.nasr_grad_device_count(self.h))
 

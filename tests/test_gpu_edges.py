@@ -268,3 +268,57 @@ def test_per_step_graphs_follow_the_resident_batch():
         np.testing.assert_allclose(nll, nllo, rtol=3e-5)
         assert rel(grads, O.flatten(go)) < 1e-4
     e.close()
+
+
+@pytest.mark.parametrize('spec,B,T', [
+    (O.ModelSpec(13, 40, 2, True, 'concat', 7), 5, 37),           # B below the 16-row padding, odd T
+    (O.ModelSpec(9, 24, 3, False, 'none', 6), 16, 50),            # one direction: only the frame-before lists
+    (O.ModelSpec(20, 128, 1, True, 'stack_reshape', 9), 20, 64),  # the literal net
+    (O.ModelSpec(20, 128, 2, True, 'concat', 9), 20, 64),         # persistent recurrence (Hp = 128), two batch blocks
+           # persistent recurrence (Hp = 128), two batch blocks
+])
+def test_ragged_batches_are_computed_on_their_frames_only(spec, B, T):
+    """DataSet.get_next_batch pads every utterance to the batch maximum (dataset.py:75-77).  With mostly-padding batches the
+    operand passes and GEMMs cover the sum(seq_len) real frame rows only (nasr.h: nasr_set_row_compaction): the results must
+    be the oracle's, and those of the same engine working on all T x B rows, whether the batch arrives by upload or through
+    the staging slots; a full-length batch is compacted only where the batch dimension's own padding (to 16) is a tenth of
+    the rows."""
+    rs = np.random.RandomState(B + T)
+    feats = rs.randn(B, T, spec.feature_size).astype(np.float32)
+    seq_len = rs.randint(1, T // 2, size=B).astype(np.int32)
+    seq_len[B // 2] = T                                     # one long utterance sets T; the others are mostly padding
+    seq_len[0] = 1
+    for b in range(B):
+        feats[b, seq_len[b]:] = 0
+    label_len = np.minimum(rs.randint(0, 6, size=B), seq_len // 2).astype(np.int32)
+    labels = np.zeros((B, 6), np.int32)
+    for b in range(B):
+        labels[b, :label_len[b]] = rs.randint(0, spec.num_classes - 1, size=label_len[b])
+    params = [p.astype(np.float32).astype(np.float64) for p in O.init_params(spec, seed=4)]
+    lo, nllo, go, logits_o = O.network_loss_and_grads(spec, params, feats, seq_len, labels, label_len)
+    e = engine_for(spec)
+    e.set_params(O.flatten(params))
+    Bp = (B + 15) // 16 * 16
+    res = {}
+    for on in (True, False):
+        e.set_row_compaction(on)
+        loss, nll, grads = e.loss_and_grads(feats, seq_len, labels, label_len)
+        assert e.resident_rows() == (int(seq_len.sum()) if on else T * Bp)
+        assert loss == pytest.approx(lo, rel=3e-5)
+        np.testing.assert_allclose(nll, nllo, rtol=3e-5, atol=1e-5)
+        assert rel(grads, O.flatten(go)) < 1e-4
+        res[on] = grads
+    assert rel(res[True], res[False]) < 2e-6
+    # through the staging slots, with another (full-length) batch resident in between
+    e.set_row_compaction(True)
+    full = np.full(B, T, np.int32)
+    e.upload_batch(feats, full, labels, label_len)
+    assert e.resident_rows() == (T * B if 10 * B <= 9 * Bp else T * Bp)
+    ticket = e.stage_batch(feats, seq_len, labels, label_len)
+    e.commit_batch(ticket)
+    assert e.resident_rows() == int(seq_len.sum())
+    e.compute_grads()
+    np.testing.assert_array_equal(e.get_grads(), res[True])
+    np.testing.assert_allclose(e.forward(feats, seq_len), logits_o, atol=2e-4)    # a forward-only batch: all rows
+    assert e.resident_rows() == T * Bp
+    e.close()
