@@ -246,8 +246,8 @@ int64_t nasr_step_token(nasr_handle h);
 int nasr_settle_token(nasr_handle h, int64_t token, int* void_out);
 int nasr_resident_frames(nasr_handle h, int64_t* frames); /* sum(seq_len) of the resident batch */
 /* Ragged batches.  DataSet.get_next_batch (dataset.py:75-77) pads every utterance to the longest of its batch and
- * tf.nn.(bidirectional_)dynamic_rnn (networks/bilstm_ctc_net.py:40-53) masks by sequence_length.  Here, when at least a
- * tenth of a training batch's T x B frame rows are such padding, the operand passes and GEMMs of a plain (Bi)LSTM stack work
+ * tf.nn.(bidirectional_)dynamic_rnn (networks/bilstm_ctc_net.py:40-53) masks by sequence_length.  Here, when at least
+ * 15 % of a training batch's T x B frame rows are such padding, the operand passes and GEMMs of a plain (Bi)LSTM stack work
  * on the frames t < seq_len[b] only (gathered on the way in, scattered on the way out); the recurrences still run T steps.
  * Results are the uncompacted ones up to summation order.  On by default (NASR_COMPACT=0 in the environment: off);
  * a change takes effect with the next batch uploaded or committed.  nasr_resident_rows: the rows those passes cover for

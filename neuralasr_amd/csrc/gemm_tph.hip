@@ -274,6 +274,7 @@ void launch_fill(float* p, float v, int n, hipStream_t st) {
 // rowmap (or NULL): logical row i of this pass is physical row rowmap[i] of src (-1: a zero row) - the COMPACTED rows of a ragged
 // batch (nasr_batch.hip: only the frames t < seq_len[b], time-major); rowmap2 replaces it for the column blocks from col2 on
 // (the two directions of a layer's output shifted by one frame in opposite directions: the recurrent weight gradient).
+template <bool MAP>
 __global__ __launch_bounds__(256) void tph_split2_kernel(const float* __restrict__ src, unsigned char* __restrict__ tpN,
                                                          unsigned char* __restrict__ tpT, int rows, int K, int ld,
                                                          const float* __restrict__ row_scale, float rs,
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(256) void tph_split2_kernel(const float* __restrict
     const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 + r < rows) {
-      const int* mp = (rowmap2 && c0 >= col2) ? rowmap2 : rowmap;
-      const int pr = mp ? mp[r0 + r] : r0 + r;
+      int pr = r0 + r;
+      if constexpr (MAP) pr = ((rowmap2 && c0 >= col2) ? rowmap2 : rowmap)[r0 + r];
       if (pr >= 0) {
         const float* s = src + (size_t)pr * ld + c0 + c;
         if (c0 + c + 4 <= K) v = *reinterpret_cast<const float4*>(s);
@@ -356,8 +357,12 @@ void launch_tph_split2(const float* src, unsigned char* tpN, unsigned char* tpT,
                        const float* row_scale, float rs, const float* col_scale, float cs, float* colpart, hipStream_t st,
                        const int* rowmap, const int* rowmap2, int col2) {
   dim3 grid((K + 63) / 64, (rows + 63) / 64);
-  hipLaunchKernelGGL(tph_split2_kernel, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld, row_scale, rs, col_scale, cs,
-                     colpart, rowmap, rowmap2, col2);
+  if (rowmap)
+    hipLaunchKernelGGL(tph_split2_kernel<true>, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld, row_scale, rs, col_scale, cs,
+                       colpart, rowmap, rowmap2, col2);
+  else
+    hipLaunchKernelGGL(tph_split2_kernel<false>, grid, dim3(256), 0, st, src, tpN, tpT, rows, K, ld, row_scale, rs, col_scale, cs,
+                       colpart, rowmap, rowmap2, col2);
 }
 
 // dst[i] = map[i] >= 0 ? src[map[i]] : fill  (row scales of a compacted operand)
@@ -377,7 +382,9 @@ void launch_gather_rows(float* dst, const float* src, const int* map, int n, flo
 // gradients that run under the BPTT launch of the layer below (nasr_api.hip, weight_grads on the side stream).
 // DBG (diagnostics of the co-residency experiment, NASR_SIDE_DBG, side launches only): 1 = no operand DMA after the first
 // step, 2 = no MFMAs - results are garbage, timing only.
-template <int TMW, int WM, int WN, int DBG = 0>
+// CMAP: the result rows are scattered by p.c_map (compacted rows of a ragged batch) - its own instantiations: the test per
+// stored element cost the plain epilogue 3 us a launch.
+template <int TMW, int WM, int WN, int DBG = 0, bool CMAP = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void gemm_tph_kernel(GemmTPHParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   constexpr int TM = 32 * TMW * WM, TN = 64 * WN;
@@ -495,8 +502,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN + 3) / 4) void gemm_tph_kern
         if (p.split_k > 1) {
           p.slabs[((size_t)bzz * p.M + row) * p.N + col] = v;
         } else {
-          const int orow = p.c_map ? p.c_map[row] : row;
-          if (orow >= 0) p.C[(size_t)bz * p.c_bstride + (size_t)orow * p.ldc + col] = v + bv;
+          if constexpr (CMAP) {
+            const int orow = p.c_map[row];
+            if (orow >= 0) p.C[(size_t)bz * p.c_bstride + (size_t)orow * p.ldc + col] = v + bv;
+          } else {
+            p.C[(size_t)bz * p.c_bstride + (size_t)row * p.ldc + col] = v + bv;
+          }
         }
       }
     }
@@ -507,9 +518,9 @@ constexpr int TPH_LDS_SIDE = 2 * 40 * HTB;     // <4,1,3>: (4 + 6) row blocks x 
 hipError_t gemm_tph_prepare() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<4, 2, 4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, TPH_LDS);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tph_kernel<3, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            TPH_LDS);
+  for (const void* f : {reinterpret_cast<const void*>(&gemm_tph_kernel<3, 2, 4>), reinterpret_cast<const void*>(&gemm_tph_kernel<4, 2, 4, 0, true>),
+                        reinterpret_cast<const void*>(&gemm_tph_kernel<3, 2, 4, 0, true>)})
+    if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TPH_LDS);
   for (const void* f : {reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3>), reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3, 1>),
                         reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3, 2>), reinterpret_cast<const void*>(&gemm_tph_kernel<4, 1, 3, 3>)})
     if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TPH_LDS_SIDE);
@@ -575,10 +586,14 @@ void launch_gemm_tph(const GemmTPHDesc& g, hipStream_t st) {
     if (p.swz) grid = dim3(8 * p.sr * p.sc * p.sz, 1, 1);
   }
   static const int side_dbg = [] { const char* e = getenv("NASR_SIDE_DBG"); return e ? atoi(e) : 0; }();
+  // rows scattered in the epilogue: main-stream products only (gemm_xproj, gemm_dx); a K-split one scatters in its reduction
+  const bool scatter = g.c_map && p.split_k == 1 && !g.side;
   if (g.side && side_dbg == 1) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3, 1>), grid, dim3(192), TPH_LDS_SIDE, st, p);
   else if (g.side && side_dbg == 2) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3, 2>), grid, dim3(192), TPH_LDS_SIDE, st, p);
   else if (g.side && side_dbg == 3) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3, 3>), grid, dim3(192), TPH_LDS_SIDE, st, p);
   else if (g.side) hipLaunchKernelGGL((gemm_tph_kernel<4, 1, 3>), grid, dim3(192), TPH_LDS_SIDE, st, p);
+  else if (scatter && tm == 192) hipLaunchKernelGGL((gemm_tph_kernel<3, 2, 4, 0, true>), grid, dim3(512), TPH_LDS, st, p);
+  else if (scatter) hipLaunchKernelGGL((gemm_tph_kernel<4, 2, 4, 0, true>), grid, dim3(512), TPH_LDS, st, p);
   else if (tm == 192) hipLaunchKernelGGL((gemm_tph_kernel<3, 2, 4>), grid, dim3(512), TPH_LDS, st, p);
   else hipLaunchKernelGGL((gemm_tph_kernel<4, 2, 4>), grid, dim3(512), TPH_LDS, st, p);
   if (p.split_k > 1) {

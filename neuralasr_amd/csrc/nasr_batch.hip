@@ -177,10 +177,11 @@ int slot_fill(nasr_ctx* h, BatchSlot* s, const float* feats, const int32_t* seq_
   s->o_cstart = s->o_labels + (size_t)B * Lm;
   s->o_cpos = s->o_cstart + (labels ? (size_t)B * (C + 1) : 0);
   s->o_rowmap = s->o_cpos + (size_t)B * Lm;
-  // compacted rows: worth it when at least a tenth of the T x Bp rows are padding (and only for training batches)
+  // compacted rows: worth it when at least 15 % of the T x Bp rows are padding (profiles/r03_row_compaction_ab.log: even at
+  // 10 %), and only for training batches
   int64_t rv = 0;
   for (int b = 0; b < B; ++b) rv += seq_len[b];
-  s->cmp = h->compactable && labels && rv * 10 <= (int64_t)T * Bp * 9;
+  s->cmp = h->compactable && labels && rv * 20 <= (int64_t)T * Bp * 17;
   s->Rv = s->cmp ? (int)rv : 0;
   s->Rvp = s->cmp ? rup((int)rv, 64) : 0;
   s->o_vrow = s->o_rowmap + (sr ? (size_t)Tp * Bp : 0);

@@ -257,7 +257,7 @@ struct nasr_ctx {
   // device arrays of the resident batch (inside cur->dmeta / cur->dfeats)
   int32_t *seq_p = nullptr, *lablen_p = nullptr, *labels_p = nullptr, *cstart_p = nullptr, *cpos_p = nullptr,
           *rowmap_p = nullptr;
-  // Ragged batches (dataset.py:75-77 pads every utterance to the batch maximum): when at least a tenth of the T x Bp frame rows
+  // Ragged batches (dataset.py:75-77 pads every utterance to the batch maximum): when at least 15 % of the T x Bp frame rows
   // are padding, the plane passes and GEMMs of a plain (Bi)LSTM stack work on the COMPACTED rows - only the frames t < seq_len[b],
   // time-major - and scatter their results back (split passes gather by vrow, GEMM epilogues scatter by it; vprev / vnext =
   // the row of the frame before / after each compacted row, -1 at an utterance's first / last frame: the h_{t-1} operand of
