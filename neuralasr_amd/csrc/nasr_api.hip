@@ -358,7 +358,7 @@ int nasr_destroy(nasr_handle h) {
     if (bs.ev_released) (void)hipEventDestroy(bs.ev_released);
   }
   for (DevBuf* b : {&h->seqbuf, &h->X0, &h->dout, &h->hstate, &h->partial, &h->dcstate, &h->dgbuf, &h->logits, &h->logz,
-                    &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->slabs,
+                    &h->alpha, &h->beta, &h->aoff, &h->boff, &h->logp, &h->nll, &h->loss, &h->slabs, &h->ctcprobs, &h->ctckexp,
                     &h->csws, &h->amax, &h->ids, &h->lens, &h->stage, &h->dgmax})
     b->release();
   for (auto& b : h->gates) b.release();
