@@ -91,17 +91,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// the lattice on probabilities (ctc_ab_lin) wants its workspaces, 32-float logit rows with a zero column to park idle states on
-static bool ctc_lin_ok(const CtcDims& d) {
-  static const bool no_lin = getenv("NASR_CTC_LIN") && getenv("NASR_CTC_LIN")[0] == '0';     // log-domain recursions only
-  return !no_lin && d.probs && d.kexp && d.fmt && d.Cp == 32 && d.C <= 31 && d.KS >= 2;
+// the engineered lattice (2b) wants its workspaces, 32-float emission rows with a spare column to park idle states on, two
+// states per lane at least and DPP (NASR_CTC_FAST=0 / NASR_CTC_DPP=0: the plain one of (2))
+static bool ctc_fast_ok(const CtcDims& d) {
+  static const bool off = (getenv("NASR_CTC_FAST") && getenv("NASR_CTC_FAST")[0] == '0') ||
+                          (getenv("NASR_CTC_DPP") && getenv("NASR_CTC_DPP")[0] == '0');
+  return !off && d.lprobs && d.goff && d.Cp == 32 && d.C <= 31 && d.KS >= 2;
 }
 
 // ------------------------------------------------------------------ (1) log partition per row
-// (probs, or NULL: the row's softmax y(t,k) = exp(x - logZ) too, zero in the columns from C on - the emissions of the
-// lattice kernel that works on probabilities)
+// (lprobs, or NULL: the row's emissions in the form the engineered lattice (2b) reads them too, log2 y(t,k) =
+// (x - logZ) log2(e), NEG in the columns from C on)
 __global__ __launch_bounds__(256) void ctc_logz_kernel(const float* __restrict__ logits, const int* __restrict__ seq_len,
-                                                       float* __restrict__ logz, float* __restrict__ probs, int Tp, int B, int Bp,
+                                                       float* __restrict__ logz, float* __restrict__ lprobs, int Tp, int B, int Bp,
                                                        int C, int Cp) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -117,13 +119,13 @@ __global__ __launch_bounds__(256) void ctc_logz_kernel(const float* __restrict__
   s = wave_sum(s);
   const float z = m + __logf(s);
   if (lane == 0) logz[row] = z;
-  if (probs)
-    for (int c = lane; c < Cp; c += 64) probs[(size_t)row * Cp + c] = c < C ? __expf(x[c] - z) : 0.f;
+  if (lprobs)
+    for (int c = lane; c < Cp; c += 64) lprobs[(size_t)row * Cp + c] = c < C ? (x[c] - z) * 1.44269504088896341f : NEG;
 }
 
 void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, float* logz, hipStream_t st) {
   const int rows = d.Tp * d.Bp;
-  hipLaunchKernelGGL(ctc_logz_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, seq_len, logz, ctc_lin_ok(d) ? d.probs : nullptr,
+  hipLaunchKernelGGL(ctc_logz_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, seq_len, logz, ctc_fast_ok(d) ? d.lprobs : nullptr,
                      d.Tp, d.B, d.Bp, d.C, d.Cp);
 }
 
@@ -313,222 +315,210 @@ __device__ __forceinline__ void ctc_ab_log(
   }
 }
 
-// ------------------------------------------------------------------ (2b) the same recursions on PROBABILITIES
-// alpha(t,u) = y(l'_u,t) (alpha(t-1,u) + alpha(t-1,u-1) [+ alpha(t-1,u-2)]): two fused multiply-adds and a multiply per state
-// and frame behind the two DPP moves, against three exp and a log in the log domain - the lattice is a chain of T dependent
-// frames on ONE wave, bound by its own instruction count (144 instructions a frame there).
-//
-// Range.  A column of alpha spans far more than fp32's exponents (at T = 500 the forward mass runs hundreds of binary orders
-// ahead of the band the posterior lives in), so every LANE carries its own binary exponent: alpha = a * 2^kme for the KS
-// states of a lane.  A neighbour's values arrive in the neighbour's scale and are brought into the lane's own by the factor
-// f = 2^(kme_n - kme), which rides in the multiply-add that sums them: no instruction more.  Every 4 frames a lane looks at its
-// own largest value and chooses the power of two kp that the emissions of the first frame of the NEXT group will carry
-// (kp_next = floor(log2 max) - kp: the level after the scale still pending, so the level is back at ~1 a group later; taken
-// from max alone it would oscillate with period 6 groups).  A lane the recursion has not reached yet (all zero) copies its
-// neighbour's exponents, so that what first arrives there is representable.  All of this is integer work off the chain.
-//
-// Emissions.  The softmax rows y(t,.) (ctc_logz_kernel: 32 floats a frame, a zero column for the idle states) come in by
-// LDS-DMA, 32 frames per 4 instructions, a chunk ahead; the lattice gathers its KS values per frame from that ring with
-// ds_read_b32, one group ahead.  No register staging, no per-frame global gathers to wait for.
-//
-// Workspace: a values [t][lane][KS] (one store per frame) and the lane exponents per GROUP of frames, kexp[g][lane].
-// An utterance whose numbers leave the range this scheme covers (|exponent step| > 100 between two rescalings or between two
-// neighbouring lanes: emission probabilities under ~1e-4 for 8 frames in a row, or no valid path at all) is FLAGGED and redone by
-// the log-domain recursion above in the same launch; fmt[b] tells ctc_grad which form the workspace of utterance b holds.
-constexpr int LIN_G = 4, LIN_CH = 32, LIN_RING = 64;
+// ------------------------------------------------------------------ (2b) the same recursions, engineered: the default
+// What (2) above spends a frame's ~600 cycles on, at KS = 3: 12 transcendentals (each issues at a quarter of the plain rate)
+// and ~100 plain instructions, of which the recursion itself needs about a third.  Here:
+//  * base-2 logarithms and the SORTED three-term sum: log2(2^a + 2^b + 2^c) = mx + log2(1 + 2^(md-mx) + 2^(mn-mx)) with
+//    v_max3 / v_med3 / v_min3 - the largest term is exactly 1, so two v_exp and one v_log per state instead of three and one;
+//  * the emissions log2 y(t,k) as dense 32-float rows (ctc_logz_kernel writes them, NEG in the columns from C on: idle states
+//    park there), brought into LDS by a THIRD wave with LDS-DMA, 32 frames of both walks per 8 instructions, a chunk ahead;
+//    the walks gather their KS values per frame from that ring with ds_read_b32 a group ahead - no per-frame global gathers,
+//    no "x - logZ" on the walk's instruction stream;
+//  * one store per frame ([t][lane][KS], wave-uniform base + 32-bit offset) and the column offset once per GROUP of 4 frames
+//    (it only changes there) instead of KS stores + a predicated fp64 store per frame with 64-bit address arithmetic;
+//  * frames past the end only in the last group's code; the next group's emissions land in the registers the group after
+//    will read (two groups per loop turn, roles swapped) instead of being copied.
+// Numerics are those of (2): rescaled columns (alpha~ = alpha - off, off bumped by the column maximum every 4 frames, fp64
+// cumulative), TF's conventions, NEG = -1e30 for "no path".  (A version on PROBABILITIES - two multiply-adds and a multiply per
+// state, binary exponents per lane - was built first: 70 us against this one's, and exact on fresh nets; but the first
+// label emitted at a frame where training has made it improbable moves a lane's level by 2^20 and more per FRAME, beyond any
+// rescaling that is not itself per frame - from step ~10 of a training run every utterance had to be redone in the log
+// domain.  Logarithms it is.)
+constexpr int FAST_G = 4, FAST_CH = 32, FAST_RING = 64;
 
-// The stores of the lattice as ONE instruction per <= 4 states.  (s_nop: a store of more than 64 bits reads its data
-// registers a cycle after it issues; hipcc keeps the next VALU write of them away from its own stores, not from these.)
-typedef float lin_f2 __attribute__((ext_vector_type(2)));
-typedef float lin_f3 __attribute__((ext_vector_type(3)));
-typedef float lin_f4 __attribute__((ext_vector_type(4)));
+typedef float fast_f2 __attribute__((ext_vector_type(2)));
+typedef float fast_f3 __attribute__((ext_vector_type(3)));
+typedef float fast_f4 __attribute__((ext_vector_type(4)));
+// The store of a frame's column as ONE instruction per <= 4 states, at wave-uniform base + 32-bit byte offset (the addressing
+// mode's own sum: one VALU add per frame, no 64-bit math).  (s_nop: a store of more than 64 bits reads its data registers a
+// cycle after it issues; hipcc keeps the next VALU write of them away from its own stores, not from these.)
 template <int KS>
-__device__ __forceinline__ void lin_store(float* dst, const float (&a)[KS]) {
+__device__ __forceinline__ void fast_store(float* base, unsigned voff, const float (&a)[KS]) {
 #pragma unroll
   for (int j = 0; j + 4 <= KS; j += 4) {
-    const lin_f4 v = {a[j], a[j + 1], a[j + 2], a[j + 3]};
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst + j), "v"(v) : "memory");
+    const fast_f4 v = {a[j], a[j + 1], a[j + 2], a[j + 3]};
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "n"(j * 4) : "memory");
   }
   constexpr int j = KS & ~3;
   if constexpr (KS % 4 == 3) {
-    const lin_f3 v = {a[j], a[j + 1], a[j + 2]};
-    asm volatile("global_store_dwordx3 %0, %1, off\n\ts_nop 1" : : "v"(dst + j), "v"(v) : "memory");
+    const fast_f3 v = {a[j], a[j + 1], a[j + 2]};
+    asm volatile("global_store_dwordx3 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "n"(j * 4) : "memory");
   } else if constexpr (KS % 4 == 2) {
-    const lin_f2 v = {a[j], a[j + 1]};
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst + j), "v"(v) : "memory");
+    const fast_f2 v = {a[j], a[j + 1]};
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(base), "n"(j * 4) : "memory");
   } else if constexpr (KS % 4 == 1) {
-    asm volatile("global_store_dword %0, %1, off" : : "v"(dst + j), "v"(a[j]) : "memory");
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(a[j]), "s"(base), "n"(j * 4) : "memory");
   }
 }
-template <int KS>
-constexpr int lin_nst() { return (KS + 3) / 4; }            // store instructions per frame
+// lane l <- lane l-1 / l+1 with `edge` at the wave's first / last lane, as in lane_up1 / lane_down1
+__device__ __forceinline__ float fast_up(float v) { return lane_up1<true>(v, NEG); }
+__device__ __forceinline__ float fast_down(float v) { return lane_down1<true>(v, NEG); }
 
-__device__ __forceinline__ int dpp_shr_i(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int dpp_shl_i(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ float pow2i(int d) { return d <= -127 ? 0.f : __int_as_float((d + 127) << 23); }
+// log2(2^a + 2^b + 2^c)
+__device__ __forceinline__ float lse3_2(float a, float b, float c) {
+  const float mx = __builtin_fmaxf(a, __builtin_fmaxf(b, c));                   // (v_max3_f32)
+  const float md = __builtin_amdgcn_fmed3f(a, b, c);
+  const float mn = __builtin_fminf(a, __builtin_fminf(b, c));                   // (v_min3_f32)
+  const float s = 1.f + __builtin_amdgcn_exp2f(md - mx) + __builtin_amdgcn_exp2f(mn - mx);
+  return mx + __builtin_amdgcn_logf(s);
+}
 
 template <int KS, bool fwd>
-__device__ __forceinline__ void ctc_lin_walk(const float* __restrict__ probs, const int* __restrict__ labels,
-                                           const int* __restrict__ label_len, const int* __restrict__ seq_len,
-                                           float* __restrict__ alpha, float* __restrict__ beta, int* __restrict__ kexp,
-                                           float* __restrict__ nll, double* __restrict__ logp_out, int Bp, int C, int Lmax, int Tws,
-                                           int KG, float* ring, float* fin, int* fink, int* bad, volatile int* sync) {
+__device__ __forceinline__ void ctc_fast_walk(const int* __restrict__ labels, const int* __restrict__ label_len,
+                                              const int* __restrict__ seq_len, float* __restrict__ alpha, float* __restrict__ beta,
+                                              double* __restrict__ goff, float* __restrict__ nll, double* __restrict__ logp_out,
+                                              const float* __restrict__ lprobs, int Bp, int C, int Lmax, int Tws, int KG, float* ring,
+                                              float* fin, int* sync) {
   static_assert(KS >= 2, "two states per lane at least: the skip transition then never reaches past the neighbour lane");
-  constexpr int G = LIN_G;
+  constexpr int G = FAST_G;
+  constexpr double LN2 = 0.693147180559945309417;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, w = fwd ? 0 : 1;
   const int L = label_len[b], Tb = seq_len[b], S = 2 * L + 1;
   const int blank = C - 1;
   const int* lab = labels + (size_t)b * Lmax;
   int ext[KS];
-  float sk[KS];                             // 1: the transition from two states away exists
+  bool skip[KS];
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
     const int s = lane * KS + i;
     const bool act = s < S;
-    ext[i] = act ? ((s & 1) ? lab[s >> 1] : blank) : 31;      // column 31 of a softmax row is zero
-    bool k2;
+    ext[i] = act ? ((s & 1) ? lab[s >> 1] : blank) : 31;      // column 31 of an emission row is NEG
     if (fwd) {
       const int e2 = (s >= 2 && (s & 1)) ? lab[(s >> 1) - 1] : blank;   // l'_{s-2}
-      k2 = act && s >= 2 && ext[i] != blank && ext[i] != e2;
+      skip[i] = act && s >= 2 && ext[i] != blank && ext[i] != e2;
     } else {
       const int e2 = (s + 2 < S && (s & 1)) ? lab[(s >> 1) + 1] : blank;   // l'_{s+2}
-      k2 = (s + 2 < S) && e2 != blank && e2 != ext[i];
+      skip[i] = (s + 2 < S) && e2 != blank && e2 != ext[i];
     }
-    sk[i] = k2 ? 1.f : 0.f;
   }
   // positions p = 0 .. Tb-2 of this wave's walk: the emission frame of position p is p+1 (alpha, producing frame p+1) or
   // Tb-1-p (beta, producing frame Tb-2-p)
   const int npos = Tb - 1;
-  auto frame_of = [&](int p) { return fwd ? p + 1 : Tb - 1 - p; };
-  float* rg = ring + w * (LIN_RING * 32);
-  const float* yb = probs + (size_t)b * 32;
-  const unsigned rstride = (unsigned)Bp * 32u * 4u;         // bytes between the rows of two frames
+  float* rg = ring + w * (FAST_RING * 32);
   // (plain LDS loads between compiler barriers: the rows change under this wave - the loader's LDS-DMA is nothing hipcc can
   //  see - so nothing may be kept from an earlier gather, and the gathers must stay behind the wait for the loader's word.
   //  Volatile accesses would do that too, but hipcc waits for EVERY outstanding store around each of them.)
   auto read_group = [&](int g, float (&e)[G][KS]) {        // emissions of positions 4g .. 4g+3
     asm volatile("" ::: "memory");
-    const float* r0 = rg + ((G * g) & (LIN_RING - 1)) * 32;
+    const float* r0 = rg + ((G * g) & (FAST_RING - 1)) * 32;
 #pragma unroll
     for (int i = 0; i < KS; ++i)
 #pragma unroll
       for (int k = 0; k < G; ++k) e[k][i] = r0[k * 32 + ext[i]];
     asm volatile("" ::: "memory");
   };
-  auto read_done = [&](float (&)[G][KS]) {};
-  // the words the three waves talk through, read and written without the waits hipcc wraps around a volatile access
+  // the words the three waves talk through, read and written without the waits hipcc wraps around a volatile access:
+  // sync[0] = chunks the loader wave has landed in the rings (both directions), sync[1 + w] = chunks this walk is done with
   const unsigned sync_lds = (unsigned)(size_t)((lds_ptr_t)sync);
-  auto sync_ld = [&](int i) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sync_lds), "n"(0) : "memory");
-    (void)i;
-    return v;
+  auto wait_ready = [&](int n) {
+    for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+      int v;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(sync_lds) : "memory");
+      if (v >= n) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
   };
   float* ws = (fwd ? alpha : beta) + (size_t)b * Tws * KS * 64;
-  int* kx = kexp + ((size_t)b * 2 + w) * KG * 64;
-  auto store = [&](int t, const float (&a)[KS]) { lin_store<KS>(ws + ((size_t)t * 64 + lane) * KS, a); };
-  // sync[0]: chunks the loader wave has landed in the rings (both directions); sync[1 + w]: chunks this walk is done with
-  auto wait_ready = [&](int n) {
-    for (unsigned spin = 0; sync_ld(0) < n && spin < (1u << 24); ++spin) __builtin_amdgcn_s_sleep(1);
-  };
+  double* go = goff + ((size_t)b * 2 + w) * KG;             // column offset of group g (frames 4g-3 .. 4g; group 0 = the start column)
+  constexpr unsigned ROWB = 64u * KS * 4u;                  // bytes of one frame's column
+  const unsigned lane_off = (unsigned)lane * (KS * 4u);
+  auto store = [&](int t, const float (&a)[KS]) { fast_store<KS>(ws, lane_off + (unsigned)t * ROWB, a); };
 
   float a[KS];
-  int kme = 0, kp = 0;
+  double A = 0.0;
   if (fwd) {
-    const float* y0 = yb;                                   // frame 0
+    const float* y0 = lprobs + (size_t)b * 32;              // frame 0
 #pragma unroll
-    for (int i = 0; i < KS; ++i) a[i] = (lane * KS + i < 2) ? y0[ext[i]] : 0.f;
+    for (int i = 0; i < KS; ++i) a[i] = (lane * KS + i < 2) ? y0[ext[i]] : NEG;
     store(0, a);
   } else {
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       const int s = lane * KS + i;
-      a[i] = (s < S && (s == S - 1 || s == S - 2)) ? 1.f : 0.f;
+      a[i] = (s < S && (s == S - 1 || s == S - 2)) ? 0.f : NEG;
     }
     store(Tb - 1, a);
   }
-  kx[lane] = 0;                                             // group 0: the column above, exponent 0
+  if (lane == 0) go[0] = 0.0;
+  // one group of 4 frames: gathers the NEXT group's emissions into en, rescales the column, then the frames (masked: the last
+  // group of a walk, where frames past the end leave the state alone)
+  auto group = [&](int g, float (&e)[G][KS], float (&en)[G][KS], auto maskedc) {
+    constexpr bool MASKED = decltype(maskedc)::value;
+    const int p0 = G * g;
+    read_group(g + 1, en);
+    {
+      float m = a[0];
+#pragma unroll
+      for (int i = 1; i < KS; ++i) m = fmaxf(m, a[i]);
+      m = wave_max_dpp(m);
+#pragma unroll
+      for (int i = 0; i < KS; ++i) a[i] = a[i] > 0.5f * NEG ? a[i] - m : NEG;
+      A += (double)m;
+      if (lane == 0) go[g + 1] = A;
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      float na[KS];
+      if (fwd) {
+        const float p1 = fast_up(a[KS - 1]), p2 = fast_up(a[KS - 2]);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          const float x1 = (i >= 1) ? a[i >= 1 ? i - 1 : 0] : p1;
+          const float x2 = (i >= 2) ? a[i >= 2 ? i - 2 : 0] : (i == 1 ? p1 : p2);
+          na[i] = e[k][i] + lse3_2(a[i], x1, skip[i] ? x2 : NEG);
+        }
+      } else {
+        float bb[KS];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) bb[i] = a[i] + e[k][i];      // states past S: NEG + NEG, rescaled back to NEG every group
+        const float n1 = fast_down(bb[0]), n2 = fast_down(bb[1]);
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          const float x1 = (i + 1 < KS) ? bb[i + 1 < KS ? i + 1 : 0] : n1;
+          const float x2 = (i + 2 < KS) ? bb[i + 2 < KS ? i + 2 : 0] : (i + 1 < KS ? n1 : n2);
+          na[i] = lse3_2(bb[i], x1, skip[i] ? x2 : NEG);
+        }
+      }
+      if constexpr (MASKED) {
+        const bool live = p0 + k < npos;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) a[i] = live ? na[i] : a[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) a[i] = na[i];
+      }
+      // (dead frames of the last group store dead copies: alpha in the rows Tb .. Tb+2 - the workspace has T+8 - beta in row 0,
+      //  whose value they are)
+      store(fwd ? p0 + k + 1 : max(Tb - 2 - p0 - k, 0), a);
+    }
+  };
   if (npos > 0) {
-    const int nch = (npos + LIN_CH - 1) / LIN_CH;
+    const int nch = (npos + FAST_CH - 1) / FAST_CH;
     wait_ready(1);
     float e[G][KS], en[G][KS];
     read_group(0, e);
-    read_done(e);
     for (int c = 0; c < nch; ++c) {
-      for (int gi = 0; gi < LIN_CH / G; ++gi) {
-        const int g = c * (LIN_CH / G) + gi, p0 = G * g;
-        if (p0 >= npos) break;
-        if (gi == LIN_CH / G - 1 && c + 1 < nch) wait_ready(c + 2);     // the next chunk's first group: normally long there
-        read_group(g + 1, en);
-        // ---- exponents (integer work, off the chain)
-        float m = a[0];
-#pragma unroll
-        for (int i = 1; i < KS; ++i) m = fmaxf(m, a[i]);
-        const int em = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
-        const bool nz = m > 0.f;
-        int kpn = nz ? em - kp : 0;
-        // lanes the recursion has not reached (all zero; they lie beyond its front: alpha's non-zero lanes are a prefix of the
-        // wave, beta's end at the last active lane) take the FRONT lane's exponents, so that what arrives there first is
-        // representable however fast the front moves (up to 8 states = 2.7 lanes a group)
-        const unsigned long long nzmask = __ballot(nz);
-        if (nzmask) {
-          const int lf = fwd ? 63 - __builtin_clzll(nzmask) : __builtin_ctzll(nzmask);
-          const int kme_f = __builtin_amdgcn_readlane(kme, lf), kp_f = __builtin_amdgcn_readlane(kp, lf);
-          const int kpn_f = __builtin_amdgcn_readlane(kpn, lf);
-          if (!nz) { kme = kme_f; kp = kp_f; kpn = kpn_f; }
-        }
-        const int nzi = nz ? 1 : 0;
-        int kme_n, kp_n, nz_n;
-        if (fwd) { kme_n = dpp_shr_i(kme, kme); kp_n = dpp_shr_i(kp, kp); nz_n = dpp_shr_i(nzi, 0); }
-        else { kme_n = dpp_shl_i(kme, kme); kp_n = dpp_shl_i(kp, kp); nz_n = dpp_shl_i(nzi, 0); }
-        const int d1 = kme_n - kme, d2 = (kme_n + kp_n) - (kme + kp);
-        if ((nz && (em < -100 || em > 100 || kp < -120 || kp > 120)) || (nz_n && (d1 > 100 || d2 > 100))) *bad = 1;
-        const float f1 = pow2i(min(d1, 100)), f2 = pow2i(min(d2, 100));
-        const float sc = pow2i(-kp);
-#pragma unroll
-        for (int i = 0; i < KS; ++i) e[0][i] *= sc;            // the first frame of the group carries 2^-kp
-        kme += kp;
-        kp = kpn;
-        asm volatile("global_store_dword %0, %1, off" : : "v"(kx + (g + 1) * 64 + lane), "v"(kme) : "memory");
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-          const bool live = p0 + k < npos;
-          float na[KS];
-          if (fwd) {
-            const float f = k == 0 ? f1 : f2;
-            const float p1 = lane_up1<true>(a[KS - 1], 0.f), p2 = lane_up1<true>(a[KS - 2], 0.f);
-#pragma unroll
-            for (int i = 0; i < KS; ++i) {
-              float x;
-              if (i == 0) x = fmaf(f * sk[0], p2, fmaf(f, p1, a[0]));
-              else if (i == 1) x = fmaf(f * sk[1], p1, a[1] + a[0]);
-              else x = fmaf(sk[i], a[i - 2 >= 0 ? i - 2 : 0], a[i] + a[i - 1]);
-              na[i] = e[k][i] * x;
-            }
-          } else {
-            float bb[KS];
-#pragma unroll
-            for (int i = 0; i < KS; ++i) bb[i] = a[i] * e[k][i];
-            const float n1 = lane_down1<true>(bb[0], 0.f), n2 = lane_down1<true>(bb[1], 0.f);
-#pragma unroll
-            for (int i = 0; i < KS; ++i) {
-              if (i == KS - 1) na[i] = fmaf(f2 * sk[i], n2, fmaf(f2, n1, bb[i]));
-              else if (i == KS - 2) na[i] = fmaf(f2 * sk[i], n1, bb[i] + bb[KS - 1]);
-              else na[i] = fmaf(sk[i], bb[i + 2 < KS ? i + 2 : 0], bb[i] + bb[i + 1]);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < KS; ++i) a[i] = live ? na[i] : a[i];
-          // (dead frames of the last group store dead copies: rows up to Tb+2 / down to -3 ... the workspace has Tws = T+8
-          //  rows and beta's walk is clamped to row 0: the store count per group stays what the counted wait above assumes)
-          store(fwd ? p0 + k + 1 : max(Tb - 2 - p0 - k, 0), a);
-        }
-        read_done(en);
-#pragma unroll
-        for (int k = 0; k < G; ++k)
-#pragma unroll
-          for (int i = 0; i < KS; ++i) e[k][i] = en[k][i];
+      // two groups per turn: the emission registers swap roles instead of being copied
+      for (int gi = 0; gi < FAST_CH / G; gi += 2) {
+        const int g = c * (FAST_CH / G) + gi;
+        if (G * g >= npos) break;
+        if (G * g + G <= npos) group(g, e, en, std::false_type{});
+        else group(g, e, en, std::true_type{});
+        if (G * (g + 1) >= npos) break;
+        if (gi + 2 == FAST_CH / G && c + 1 < nch) wait_ready(c + 2);     // the next chunk's first group: normally long there
+        if (G * (g + 1) + G <= npos) group(g + 1, en, e, std::false_type{});
+        else group(g + 1, en, e, std::true_type{});
       }
       // every gather from this chunk's rows has returned (their values were used above): the rows may be reused
       asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1 offset:%2" : : "v"(sync_lds), "v"(c + 1), "n"(4 * (1 + w)) : "memory");
@@ -537,15 +527,11 @@ __device__ __forceinline__ void ctc_lin_walk(const float* __restrict__ probs, co
   if (fwd) {
 #pragma unroll
     for (int i = 0; i < KS; ++i) fin[lane * KS + i] = a[i];
-    fink[lane] = kme;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     if (lane == 0) {
-      const int s1 = S - 1, s2 = S - 2;
-      const int k1 = fink[s1 / KS], k2 = s2 >= 0 ? fink[s2 / KS] : k1;
-      const int km = max(k1, k2);
-      const double x = ldexp((double)fin[s1], k1 - km) + (s2 >= 0 ? ldexp((double)fin[s2], k2 - km) : 0.0);
-      if (!(x > 0.0) || !(x < 1e300)) *bad = 1;      // no path, or nothing finite left of it: the log-domain pass says which
-      const double lp = (double)km * 0.693147180559945309417 + log(x);
+      const float x = fin[S - 1];
+      const float y = S > 1 ? fin[S - 2] : NEG;
+      const double lp = (A + (double)lse3_2(x, y, NEG)) * LN2;
       logp_out[b] = lp;
       nll[b] = (float)(-lp);
     }
@@ -555,12 +541,12 @@ __device__ __forceinline__ void ctc_lin_walk(const float* __restrict__ probs, co
 // wave 2: the emissions' way into LDS.  Chunk n (32 positions of both walks) goes to the ring half chunk n-2 was in, once both
 // walks are done with that one; its LDS-DMA is this wave's only vector-memory traffic, so one s_waitcnt vmcnt(0) says it
 // has landed (a walk's own stores would sit in the same counter, and loads and stores do not retire in order).
-__device__ __forceinline__ void ctc_lin_loader(const float* __restrict__ probs, const int* __restrict__ seq_len, int Bp, float* ring,
-                                               volatile int* sync) {
+__device__ __forceinline__ void ctc_fast_loader(const float* __restrict__ lprobs, const int* __restrict__ seq_len, int Bp, float* ring,
+                                                volatile int* sync) {
   const int b = blockIdx.x, lane = threadIdx.x & 63;
   const int Tb = seq_len[b], npos = Tb - 1;
-  const int nch = (npos + LIN_CH - 1) / LIN_CH;
-  const char* yb = reinterpret_cast<const char*>(probs + (size_t)b * 32);
+  const int nch = (npos + FAST_CH - 1) / FAST_CH;
+  const char* yb = reinterpret_cast<const char*>(lprobs + (size_t)b * 32);
   const unsigned rstride = (unsigned)Bp * 32u * 4u;         // bytes between the rows of two frames
   for (int n = 0; n < nch; ++n) {
     if (n >= 2)
@@ -569,10 +555,10 @@ __device__ __forceinline__ void ctc_lin_loader(const float* __restrict__ probs, 
     for (int w = 0; w < 2; ++w)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int p = min(LIN_CH * n + 8 * q + (lane >> 3), npos - 1);          // (clamped to the last position)
+        const int p = min(FAST_CH * n + 8 * q + (lane >> 3), npos - 1);          // (clamped to the last position)
         const int f = w == 0 ? p + 1 : Tb - 1 - p;
         const char* g = yb + (size_t)((unsigned)f * rstride) + (lane & 7) * 16;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(ring + w * (LIN_RING * 32) + (((LIN_CH * n) & (LIN_RING - 1)) + 8 * q) * 32),
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(ring + w * (FAST_RING * 32) + (((FAST_CH * n) & (FAST_RING - 1)) + 8 * q) * 32),
                                          16, 0, 0);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -580,64 +566,44 @@ __device__ __forceinline__ void ctc_lin_loader(const float* __restrict__ probs, 
   }
 }
 
-template <int KS>
-__device__ __forceinline__ void ctc_ab_lin(const float* __restrict__ probs, const int* __restrict__ labels,
-                                           const int* __restrict__ label_len, const int* __restrict__ seq_len,
-                                           float* __restrict__ alpha, float* __restrict__ beta, int* __restrict__ kexp,
-                                           float* __restrict__ nll, double* __restrict__ logp_out, int Bp, int C, int Lmax, int Tws,
-                                           int KG, float* ring, float* fin, int* fink, int* bad, volatile int* sync) {
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (w == 0)
-    ctc_lin_walk<KS, true>(probs, labels, label_len, seq_len, alpha, beta, kexp, nll, logp_out, Bp, C, Lmax, Tws, KG, ring, fin, fink, bad,
-                           sync);
-  else if (w == 1)
-    ctc_lin_walk<KS, false>(probs, labels, label_len, seq_len, alpha, beta, kexp, nll, logp_out, Bp, C, Lmax, Tws, KG, ring, fin, fink,
-                            bad, sync);
-  else
-    ctc_lin_loader(probs, seq_len, Bp, ring, sync);
-}
-
-// one workgroup per utterance, wave 0 = alpha, wave 1 = beta: on probabilities (LIN), redone in the log domain where flagged
-template <int KS, bool DPP, bool LIN>
-__global__ __launch_bounds__(LIN ? 192 : 128) void ctc_alpha_beta_kernel(
-    const float* __restrict__ logits, const float* __restrict__ logz, const float* __restrict__ probs,
+// one workgroup per utterance: wave 0 = alpha, wave 1 = beta, (FAST) wave 2 = the emissions' loader
+template <int KS, bool DPP, bool FAST>
+__global__ __launch_bounds__(FAST ? 192 : 128) void ctc_alpha_beta_kernel(
+    const float* __restrict__ logits, const float* __restrict__ logz, const float* __restrict__ lprobs,
     const int* __restrict__ labels, const int* __restrict__ label_len, const int* __restrict__ seq_len,
     float* __restrict__ alpha, float* __restrict__ beta, double* __restrict__ aoff, double* __restrict__ boff,
-    int* __restrict__ kexp, float* __restrict__ nll, double* __restrict__ logp_out, int* __restrict__ fmt, int Bp, int Cp, int C,
-    int Lmax, int Tws, int KG) {
+    double* __restrict__ goff, float* __restrict__ nll, double* __restrict__ logp_out, int Bp, int Cp, int C, int Lmax, int Tws,
+    int KG) {
   __shared__ float fin[64 * KS];
-  if constexpr (LIN) {
-    __shared__ __attribute__((aligned(1024))) float ring[2 * LIN_RING * 32];
-    __shared__ int fink[64];
-    __shared__ int bad;
+  if constexpr (FAST) {
+    __shared__ __attribute__((aligned(1024))) float ring[2 * FAST_RING * 32];
     __shared__ int sync[3];
     if (threadIdx.x < 3) sync[threadIdx.x] = 0;
-    if (threadIdx.x == 0) bad = 0;
     __syncthreads();
-    ctc_ab_lin<(KS >= 2 ? KS : 2)>(probs, labels, label_len, seq_len, alpha, beta, kexp, nll, logp_out, Bp, C, Lmax, Tws, KG, ring,
-                                   fin, fink, &bad, sync);
-    __syncthreads();
-    if (!bad) {
-      if (threadIdx.x == 0) fmt[blockIdx.x] = 0;
-      return;
-    }
-    if (threadIdx.x >= 128) return;      // the loader wave has no part in the log-domain pass
+    constexpr int K2 = KS >= 2 ? KS : 2;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w == 0)
+      ctc_fast_walk<K2, true>(labels, label_len, seq_len, alpha, beta, goff, nll, logp_out, lprobs, Bp, C, Lmax, Tws, KG, ring, fin, sync);
+    else if (w == 1)
+      ctc_fast_walk<K2, false>(labels, label_len, seq_len, alpha, beta, goff, nll, logp_out, lprobs, Bp, C, Lmax, Tws, KG, ring, fin, sync);
+    else
+      ctc_fast_loader(lprobs, seq_len, Bp, ring, sync);
+  } else {
+    ctc_ab_log<KS, DPP>(logits, logz, labels, label_len, seq_len, alpha, beta, aoff, boff, nll, logp_out, Bp, Cp, C, Lmax, Tws, fin);
   }
-  ctc_ab_log<KS, DPP>(logits, logz, labels, label_len, seq_len, alpha, beta, aoff, boff, nll, logp_out, Bp, Cp, C, Lmax, Tws, fin);
-  if (fmt && threadIdx.x == 0) fmt[blockIdx.x] = 1;
 }
 
 void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,
                            const int* label_len, const int* seq_len, float* alpha, float* beta, double* aoff,
                            double* boff, float* nll, double* logp, hipStream_t st) {
   static const bool no_dpp = getenv("NASR_CTC_DPP") && getenv("NASR_CTC_DPP")[0] == '0';
-  const bool lin = ctc_lin_ok(d) && !no_dpp;
-  const int KG = d.Tws / LIN_G + 3;
-#define NASR_AB2(K, D, LN)                                                                                               \
-  hipLaunchKernelGGL((ctc_alpha_beta_kernel<K, D, LN>), dim3(d.B), dim3(LN ? 192 : 128), 0, st, logits, logz, d.probs, labels, \
-                     label_len, seq_len, alpha, beta, aoff, boff, d.kexp, nll, logp, d.fmt, d.Bp, d.Cp, d.C, d.Lmax, d.Tws, KG)
+  const bool fast = ctc_fast_ok(d);
+  const int KG = d.Tws / FAST_G + 3;
+#define NASR_AB2(K, D, F)                                                                                                \
+  hipLaunchKernelGGL((ctc_alpha_beta_kernel<K, D, F>), dim3(d.B), dim3(F ? 192 : 128), 0, st, logits, logz, d.lprobs, labels, \
+                     label_len, seq_len, alpha, beta, aoff, boff, d.goff, nll, logp, d.Bp, d.Cp, d.C, d.Lmax, d.Tws, KG)
 #define NASR_AB(K)                                                                                                       \
-  if (lin) NASR_AB2(K, true, true);                                                                                      \
+  if (fast) NASR_AB2(K, true, true);                                                                                     \
   else if (no_dpp) NASR_AB2(K, false, false);                                                                            \
   else NASR_AB2(K, true, false)
   switch (d.KS) {
@@ -652,6 +618,7 @@ void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* l
     case 9: case 10: case 11: case 12: NASR_AB(12); break;
     default: NASR_AB(16); break;
   }
+#undef NASR_AB2
 #undef NASR_AB2
 #undef NASR_AB
 }
@@ -668,9 +635,9 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logit
                                                        const int* __restrict__ cstart, const int* __restrict__ cpos,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        const double* __restrict__ aoff, const double* __restrict__ boff,
-                                                       const double* __restrict__ logp, const int* __restrict__ kexp,
-                                                       const int* __restrict__ fmt, float scale, int Tp, int B, int Bp, int C,
-                                                       int Cp, int Lmax, int KS, int Tws, int KG) {
+                                                       const double* __restrict__ logp, const double* __restrict__ goff,
+                                                       float scale, int Tp, int B, int Bp, int C, int Cp, int Lmax, int KS,
+                                                       int Tws, int KG) {
   extern __shared__ __attribute__((aligned(16))) float wl_all[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + wv;
@@ -686,25 +653,15 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(float* __restrict__ logit
   const float* al = alpha + ((size_t)b * Tws + t) * KS * 64;
   const float* be = beta + ((size_t)b * Tws + t) * KS * 64;
   float blank = 0.f;
-  if (fmt && fmt[b] == 0) {
-    // probabilities a * 2^k, [lane][KS] per frame, one exponent per lane and group of 4 frames (ctc_ab_lin); the product as a
-    // sum of logarithms: alpha beta may be far outside fp32 where the posterior is not
+  if (goff) {
+    // the workspace of the engineered lattice: base-2 logarithms, [lane][KS] per frame, one column offset per group of 4
+    // frames and walk
     const int Tb = seq_len[b];
-    const int ga = t == 0 ? 0 : 1 + (t - 1) / LIN_G, gb = t == Tb - 1 ? 0 : 1 + (Tb - 2 - t) / LIN_G;
-    const int ka = kexp[((size_t)b * 2 * KG + ga) * 64 + lane], kb = kexp[(((size_t)b * 2 + 1) * KG + gb) * 64 + lane];
-    const double lp2 = -logp[b] * 1.44269504088896341;        // posterior = a_alpha a_beta 2^(ka + kb + lp2)
-    const double lpi = floor(lp2);
-    const int E0 = ka + kb + (int)lpi;
-    const float cm = exp2f((float)(lp2 - lpi));                // in [1, 2)
+    const int ga = t == 0 ? 0 : 1 + (t - 1) / FAST_G, gb = t == Tb - 1 ? 0 : 1 + (Tb - 2 - t) / FAST_G;
+    const float coff2 = (float)(goff[(size_t)b * 2 * KG + ga] + goff[((size_t)b * 2 + 1) * KG + gb] - logp[b] * 1.44269504088896341);
     for (int i = 0; i < KS; ++i) {
       const int s = lane * KS + i;
-      const float av = al[lane * KS + i], bv = be[lane * KS + i];
-      float wgt = 0.f;
-      if (s < S && av > 0.f && bv > 0.f) {
-        int ea, eb;
-        const float ma = frexpf(av, &ea), mb = frexpf(bv, &eb);     // mantissas in [0.5, 1): their product cannot leave fp32
-        wgt = ldexpf(ma * mb * cm, min(max(E0 + ea + eb, -200), 100));
-      }
+      const float wgt = s < S ? exp2f(al[lane * KS + i] + be[lane * KS + i] + coff2) : 0.f;
       wl[s] = wgt;
       if (!(s & 1)) blank += wgt;
     }
@@ -743,8 +700,8 @@ void launch_ctc_grad(const CtcDims& d, float* logits, const float* logz, const i
   const int rows = d.Tp * d.Bp;
   const int rpb = 4;
   hipLaunchKernelGGL(ctc_grad_kernel, dim3((rows + rpb - 1) / rpb), dim3(64 * rpb), (size_t)rpb * d.KS * 64 * 4, st, logits,
-                     logz, label_len, seq_len, cstart, cpos, alpha, beta, aoff, boff, logp, d.kexp, ctc_lin_ok(d) ? d.fmt : nullptr, scale,
-                     d.Tp, d.B, d.Bp, d.C, d.Cp, d.Lmax, d.KS, d.Tws, d.Tws / LIN_G + 3);
+                     logz, label_len, seq_len, cstart, cpos, alpha, beta, aoff, boff, logp, ctc_fast_ok(d) ? d.goff : nullptr, scale,
+                     d.Tp, d.B, d.Bp, d.C, d.Cp, d.Lmax, d.KS, d.Tws, d.Tws / FAST_G + 3);
 }
 
 // mean of n floats (n small: the batch), fixed order

@@ -195,10 +195,9 @@ struct CtcDims {
   int B, Bp, C, Cp, Lmax;
   int KS;      // states per lane: ceil((2*Lmax+1)/64)
   int Tws;     // rows of the alpha/beta workspace per utterance (T + 8: a group of up to 8 frames may run past the last one)
-  // workspaces of the lattice on probabilities (ctc.hip: ctc_ab_lin), or NULL (log-domain recursions only):
-  float* probs = nullptr;   // [T'][Bp][Cp] softmax rows (launch_ctc_logz writes them)
-  int* kexp = nullptr;      // [B][2][Tws/4 + 3][64] lane exponents per group of 4 frames
-  int* fmt = nullptr;       // [B] form of utterance b's alpha/beta workspace: 0 probabilities, 1 logarithms
+  // workspaces of the engineered lattice (ctc.hip (2b)), or NULL (the plain one only):
+  float* lprobs = nullptr;  // [T'][Bp][Cp] emission rows log2 y(t,k) (launch_ctc_logz writes them)
+  double* goff = nullptr;   // [B][2][Tws/4 + 3] column offsets per walk and group of 4 frames
 };
 void launch_ctc_logz(const CtcDims& d, const float* logits, const int* seq_len, float* logz, hipStream_t st);
 void launch_ctc_alpha_beta(const CtcDims& d, const float* logits, const float* logz, const int* labels,

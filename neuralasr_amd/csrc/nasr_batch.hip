@@ -62,14 +62,14 @@ int ensure_shape(nasr_ctx* h, int B, int T, int Lmax) {
   }
   ok &= h->logits.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
   ok &= h->logz.ensure((size_t)Tp * Bp * 4, &grew);
-  const int KSa = KS <= 1 ? 2 : KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations (two states per lane at least: ctc_ab_lin)
+  const int KSa = KS <= 1 ? 2 : KS <= 8 ? KS : (KS <= 12 ? 12 : 16);   // kernel instantiations (two states per lane at least: ctc.hip (2b))
   ok &= h->alpha.ensure((size_t)B * (T + 8) * KSa * 64 * 4, &grew);
   ok &= h->beta.ensure((size_t)B * (T + 8) * KSa * 64 * 4, &grew);
   ok &= h->aoff.ensure((size_t)B * (T + 8) * 8, &grew);
   ok &= h->boff.ensure((size_t)B * (T + 8) * 8, &grew);
-  ok &= h->logp.ensure((size_t)Bp * 12, &grew);     // log p per utterance (fp64) + the form of its alpha / beta workspace (int)
-  ok &= h->ctcprobs.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);
-  ok &= h->ctckexp.ensure((size_t)B * 2 * ((T + 8) / 4 + 3) * 64 * 4, &grew);
+  ok &= h->logp.ensure((size_t)Bp * 8, &grew);
+  ok &= h->ctcprobs.ensure((size_t)Tp * Bp * h->Cp * 4, &grew);              // emission rows of the CTC lattice (ctc.hip (2b))
+  ok &= h->ctckexp.ensure((size_t)B * 2 * ((T + 8) / 4 + 3) * 8, &grew);     // its column offsets per group of frames
   ok &= h->nll.ensure((size_t)Bp * 4, &grew);
   ok &= h->loss.ensure(16, &grew);
   int csw = std::max(D * N4, h->Cp);

@@ -282,7 +282,7 @@ struct nasr_ctx {
   DevBuf XTP, X0TTP, GTP, GTTP;   // tiled-plane copies of activations / dG
   std::vector<DevBuf> OTT;        // per layer: planes of out[l] with the frame index as contraction index (weight gradients)
   std::vector<char> ott_valid;    // ... written by the forward pass of this step already (together with the planes of layer l+1's input)
-  DevBuf ctcprobs, ctckexp;                  // softmax rows and lane exponents of the CTC lattice on probabilities (ctc.hip)
+  DevBuf ctcprobs, ctckexp;                  // emission rows and column offsets of the CTC lattice (ctc.hip (2b))
   DevBuf seqbuf, X0, logits, logz, alpha, beta, aoff, boff, logp, nll, loss, slabs, csws, amax, ids, lens,
       stage;
   std::vector<DevBuf> gates, outb, cbuf;

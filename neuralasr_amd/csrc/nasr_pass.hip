@@ -291,7 +291,7 @@ CtcDims ctc_dims(nasr_ctx* h) {
   CtcDims d;
   d.Tp = h->Tp; d.B = h->B; d.Bp = h->Bp; d.C = h->C; d.Cp = h->Cp; d.Lmax = std::max(h->Lmax, 1);
   d.KS = h->KS; d.Tws = h->T + 8;
-  d.probs = h->ctcprobs.as<float>(); d.kexp = h->ctckexp.as<int>(); d.fmt = reinterpret_cast<int*>(h->logp.as<double>() + h->Bp);
+  d.lprobs = h->ctcprobs.as<float>(); d.goff = h->ctckexp.as<double>();
   return d;
 }
 

@@ -322,3 +322,39 @@ def test_ragged_batches_are_computed_on_their_frames_only(spec, B, T):
     np.testing.assert_allclose(e.forward(feats, seq_len), logits_o, atol=2e-4)    # a forward-only batch: all rows
     assert e.resident_rows() == T * Bp
     e.close()
+
+
+def test_ctc_lattice_on_flat_sharp_and_pinned_posteriors():
+    """csrc/ctc.hip (2b), the default alpha / beta kernel (sorted base-2 three-term sums, emissions staged through LDS by a
+    loader wave, columns rescaled every 4 frames): the oracle's loss and gradients (tf.nn.ctc_loss, networks/tfnetwork.py:58-59)
+    on a fresh net, on the same net with its projection scaled by 60 (posteriors as sharp as a trained net's: most labels
+    far below 1e-20 at most frames, a level that moves by 2^80 from one frame to the next) and on an utterance whose 35
+    identical labels need 69 of its 70 frames (a handful of paths, every frame pinned)."""
+    spec = O.ModelSpec(8, 16, 1, True, 'concat', 9)
+    B, T = 6, 70
+    rs = np.random.RandomState(11)
+    feats = rs.randn(B, T, spec.feature_size).astype(np.float32)
+    seq_len = np.array([70, 70, 64, 51, 70, 33], np.int32)
+    for b in range(B):
+        feats[b, seq_len[b]:] = 0
+    label_len = np.array([12, 1, 20, 9, 30, 5], np.int32)
+    labels = np.zeros((B, 35), np.int32)
+    for b in range(B):
+        labels[b, :label_len[b]] = rs.randint(0, spec.num_classes - 1, size=label_len[b])
+    base = [p.astype(np.float32).astype(np.float64) for p in O.init_params(spec, seed=5)]
+    e = engine_for(spec)
+    names = [t[0] for t in e.tensors()]
+    assert 'W' in names and 'b' in names
+    pinned = labels.copy()
+    pinned[0, :] = 3
+    pinned_len = label_len.copy()
+    pinned_len[0] = 35
+    for scale, lab, ll in ((1.0, labels, label_len), (60.0, labels, label_len), (1.0, pinned, pinned_len)):
+        params = [p * (scale if n in ('W', 'b') else 1.0) for n, p in zip(names, base)]
+        e.set_params(O.flatten(params))
+        loss, nll, grads = e.loss_and_grads(feats, seq_len, lab, ll)
+        lo, nllo, go, _ = O.network_loss_and_grads(spec, params, feats, seq_len, lab, ll)
+        assert loss == pytest.approx(lo, rel=3e-5)
+        np.testing.assert_allclose(nll, nllo, rtol=3e-5, atol=1e-5)
+        assert rel(grads, O.flatten(go)) < 1e-4
+    e.close()

@@ -1,8 +1,9 @@
-// ctcbench.hip — the CTC kernels alone: the lattice on probabilities (ctc.hip: ctc_ab_lin) against the log-domain recursion on
-// the same logits - nll, the gradient wrt the logits (first frame that differs) and the time of each.
+// ctcbench.hip — the CTC kernels alone: the engineered lattice (ctc.hip (2b)) against the plain one of (2) on the same logits -
+// nll, the gradient wrt the logits (largest difference and where) and the time of each.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ctcbench.hip -o tools/sb_ctc
 //   tools/sb_ctc [B=16] [T=500] [C=29] [Lmin=40] [Lmax=80] [sharp=1.0] [ragged=0]
 #include "../neuralasr_amd/csrc/ctc.hip"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,9 +48,8 @@ int main(int argc, char** argv) {
   float *logits = dev<float>(nl), *logz = dev<float>((size_t)T * Bp), *alpha = dev<float>(nws), *beta = dev<float>(nws), *nll = dev<float>(Bp);
   double *aoff = dev<double>((size_t)B * d.Tws), *boff = dev<double>((size_t)B * d.Tws), *logp = dev<double>(Bp);
   int *dseq = dev<int>(Bp), *dll = dev<int>(B), *dlab = dev<int>(lab.size()), *dcs = dev<int>(cstart.size()), *dcp = dev<int>(cpos.size());
-  float* probs = dev<float>(nl);
-  int* kexp = dev<int>((size_t)B * 2 * (d.Tws / 4 + 3) * 64);
-  int* fmt = dev<int>(Bp);
+  float* lprobs = dev<float>(nl);
+  double* goff = dev<double>((size_t)B * 2 * (d.Tws / 4 + 3));
   CK(hipMemcpy(dseq, seq.data(), Bp * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dll, ll.data(), B * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dlab, lab.data(), lab.size() * 4, hipMemcpyHostToDevice));
@@ -58,11 +58,12 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<float> grad[2], nllh[2];
-  std::vector<int> fmth(Bp, -1);
-  for (int mode = 0; mode < 2; ++mode) {      // 0: log domain only, 1: probabilities (+ log-domain redo where flagged)
+  for (int mode = 0; mode < 2; ++mode) {      // 0: the plain lattice, 1: the engineered one
     CtcDims dd = d;
-    if (mode == 1) { dd.probs = probs; dd.kexp = kexp; dd.fmt = fmt; }
+    if (mode == 1) { dd.lprobs = lprobs; dd.goff = goff; }
     float best = 1e9f;
+    std::vector<float> prev(nl), cur(nl);
+    int unequal = 0;
     for (int it = 0; it < 6; ++it) {
       CK(hipMemcpyAsync(logits, lg.data(), nl * 4, hipMemcpyHostToDevice, st));
       launch_ctc_logz(dd, logits, dseq, logz, st);
@@ -72,12 +73,68 @@ int main(int argc, char** argv) {
       launch_ctc_grad(dd, logits, logz, dll, dseq, dcs, dcp, alpha, beta, aoff, boff, logp, 1.f, st);
       CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+      CK(hipMemcpy(cur.data(), logits, nl * 4, hipMemcpyDeviceToHost));
+      if (it > 0 && memcmp(cur.data(), prev.data(), nl * 4) != 0) ++unequal;
+      prev.swap(cur);
     }
+    if (unequal) printf("  !! %d of 5 repeats gave other gradient bits\n", unequal);
     grad[mode].resize(nl); nllh[mode].resize(Bp);
     CK(hipMemcpy(grad[mode].data(), logits, nl * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(nllh[mode].data(), nll, Bp * 4, hipMemcpyDeviceToHost));
-    if (mode == 1) CK(hipMemcpy(fmth.data(), fmt, Bp * 4, hipMemcpyDeviceToHost));
-    printf("%s: alpha/beta kernel %.1f us (B %d T %d C %d KS %d)\n", mode ? "probabilities" : "log domain   ", best * 1e3, B, T, C, d.KS);
+    printf("%s: alpha/beta kernel %.1f us (B %d T %d C %d KS %d)\n", mode ? "engineered" : "plain     ", best * 1e3, B, T, C, d.KS);
+  }
+  // fp64 reference on the host: log-domain alpha / beta, TF's conventions (ctc.hip header)
+  std::vector<double> gref(nl, 0.0), nllref(B, 0.0);
+  for (int b = 0; b < B; ++b) {
+    const int Tb = seq[b], L = ll[b], S = 2 * L + 1;
+    auto ext = [&](int s) { return (s & 1) ? lab[(size_t)b * Lmax + (s >> 1)] : C - 1; };
+    auto lse = [](double x, double y) { if (x < y) std::swap(x, y); return y < -1e29 ? x : x + log1p(exp(y - x)); };
+    std::vector<double> lp((size_t)Tb * C), al((size_t)Tb * S, -1e30), be((size_t)Tb * S, -1e30);
+    for (int t = 0; t < Tb; ++t) {
+      const float* x = &lg[((size_t)t * Bp + b) * Cp];
+      double m = -1e300; for (int c = 0; c < C; ++c) m = std::max(m, (double)x[c]);
+      double z = 0; for (int c = 0; c < C; ++c) z += exp(x[c] - m);
+      z = m + log(z);
+      for (int c = 0; c < C; ++c) lp[(size_t)t * C + c] = x[c] - z;
+    }
+    al[0] = lp[ext(0)]; if (S > 1) al[1] = lp[ext(1)];
+    for (int t = 1; t < Tb; ++t)
+      for (int s = 0; s < S; ++s) {
+        double v = al[(size_t)(t - 1) * S + s];
+        if (s >= 1) v = lse(v, al[(size_t)(t - 1) * S + s - 1]);
+        if (s >= 2 && (s & 1) && ext(s) != ext(s - 2)) v = lse(v, al[(size_t)(t - 1) * S + s - 2]);
+        al[(size_t)t * S + s] = v < -1e29 ? -1e30 : v + lp[(size_t)t * C + ext(s)];
+      }
+    be[(size_t)(Tb - 1) * S + S - 1] = 0; if (S > 1) be[(size_t)(Tb - 1) * S + S - 2] = 0;
+    for (int t = Tb - 2; t >= 0; --t)
+      for (int s = 0; s < S; ++s) {
+        auto term = [&](int u) { const double q = be[(size_t)(t + 1) * S + u]; return q < -1e29 ? -1e30 : q + lp[(size_t)(t + 1) * C + ext(u)]; };
+        double v = term(s);
+        if (s + 1 < S) v = lse(v, term(s + 1));
+        if (s + 2 < S && (s & 1) && ext(s + 2) != ext(s)) v = lse(v, term(s + 2));
+        be[(size_t)t * S + s] = v;
+      }
+    double logp = al[(size_t)(Tb - 1) * S + S - 1];
+    if (S > 1) logp = lse(logp, al[(size_t)(Tb - 1) * S + S - 2]);
+    nllref[b] = -logp;
+    for (int t = 0; t < Tb; ++t) {
+      std::vector<double> post(C, 0.0);
+      for (int s = 0; s < S; ++s) post[ext(s)] += exp(al[(size_t)t * S + s] + be[(size_t)t * S + s] - logp);
+      for (int c = 0; c < C; ++c) gref[((size_t)t * Bp + b) * Cp + c] = exp(lp[(size_t)t * C + c]) - post[c];
+    }
+  }
+  for (int mode = 0; mode < 2; ++mode) {
+    double num = 0, den = 0, nw = 0;
+    for (int b = 0; b < B; ++b) {
+      nw = std::max(nw, fabs(nllh[mode][b] - nllref[b]) / std::max(1.0, fabs(nllref[b])));
+      for (int t = 0; t < seq[b]; ++t)
+        for (int c = 0; c < C; ++c) {
+          const size_t i = ((size_t)t * Bp + b) * Cp + c;
+          const double df = grad[mode][i] - gref[i];
+          num += df * df; den += gref[i] * gref[i];
+        }
+    }
+    printf("%s vs fp64: gradient rel %.2e, worst nll rel %.2e\n", mode ? "engineered" : "plain     ", sqrt(num / (den > 0 ? den : 1)), nw);
   }
   for (int b = 0; b < B; ++b) {
     double num = 0, den = 0, worst = 0; int wt = -1, wc = -1;
@@ -88,8 +145,8 @@ int main(int argc, char** argv) {
         num += df * df; den += (double)grad[0][i] * grad[0][i];
         if (fabs(df) > worst) { worst = fabs(df); wt = t; wc = c; }
       }
-    printf("  utt %2d  T %3d L %3d  form %d  nll %.6f / %.6f  grad rel %.2e  worst |d| %.2e at t %d class %d\n", b, seq[b], ll[b], fmth[b],
-           nllh[1][b], nllh[0][b], sqrt(num / (den > 0 ? den : 1)), worst, wt, wc);
+    printf("  utt %2d  T %3d L %3d  nll %.6f / %.6f  grad rel %.2e  worst |d| %.2e at t %d class %d\n", b, seq[b], ll[b], nllh[1][b],
+           nllh[0][b], sqrt(num / (den > 0 ? den : 1)), worst, wt, wc);
   }
   return 0;
 }
