@@ -248,6 +248,9 @@ int nasr_create(const nasr_model_cfg* cfg, int device_id, void* stream, nasr_han
   h->Ybuf.resize(h->ndense);
   h->dYbuf.resize(h->ndense);
   if (hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking) != hipSuccess) return bail(NASR_ERR_HIP, "hipStreamCreate (copy stream) failed");
+  if (hipStreamCreateWithFlags(&h->d2h, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_snap, hipEventDisableTiming) != hipSuccess)
+    return bail(NASR_ERR_HIP, "hipStreamCreate (results stream) failed");
   {
     const char* eo = getenv("NASR_WGRAD_OVERLAP");
     const bool eligible = h->persist && h->Hp == 512 && h->L > 1;
@@ -339,9 +342,16 @@ int nasr_destroy(nasr_handle h) {
     for (auto& v : *vec) v.release();
   (void)nasr_comm_destroy(h);
   if (h->adam_dev) (void)hipFree(h->adam_dev);
+  if (h->d2h) {
+    (void)hipStreamSynchronize(h->d2h);
+    (void)hipStreamDestroy(h->d2h);
+  }
+  if (h->ev_snap) (void)hipEventDestroy(h->ev_snap);
+  h->logits_snap.release();
   for (auto& r : h->res) {
     if (r.host) (void)hipHostFree(r.host);
     if (r.stamp) (void)hipHostFree(r.stamp);
+    if (r.ev_lg) (void)hipEventDestroy(r.ev_lg);
   }
   for (auto& e : h->endw)
     if (e.host) (void)hipHostFree(e.host);
@@ -800,6 +810,7 @@ int nasr_get_step_logits(nasr_handle h, float* logits_out) {
   if (!r.valid || !r.logits)
     return h->fail(NASR_ERR_STATE, "nasr_get_step_logits: no step with nasr_set_step_decode(h, 3) has been enqueued");
   if (!wait_stamp(r.stamp, r.seq, 60.0)) return h->fail(NASR_ERR_HIP, "nasr_get_step_logits: the step's results did not arrive within 60 s");
+  HIPCHK(h, hipEventSynchronize(r.ev_lg));          // the logits travel on a stream of their own (ctc_forward)
   const size_t ids_bytes = 8 + (size_t)r.Bp * 4 + (size_t)r.B * r.Tp * 4;
   const float* src = reinterpret_cast<const float*>(static_cast<const char*>(r.host) + (ids_bytes + 255) / 256 * 256);
   for (int t = 0; t < r.Tp; ++t)

@@ -234,7 +234,8 @@ struct nasr_ctx {
   // forward pass, and the greedy decode are copied to pinned memory right behind the CTC forward kernels; the fault
   // word at the END of a step is copied behind its Adam launch (nasr_settle_step).  Two slots each: the host may be
   // one step ahead of the device.
-  struct StepRes { void* host = nullptr; size_t cap = 0; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int B = 0, Bp = 0, Tp = 0; bool logits = false; };
+  struct StepRes { void* host = nullptr; size_t cap = 0; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int B = 0, Bp = 0, Tp = 0; bool logits = false;
+                   hipEvent_t ev_lg = nullptr; };   // ev_lg: the step's logits have landed in host memory (stream d2h)
   StepRes res[2];
   int res_cur = 0;
   struct StepEnd { float* host = nullptr; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int64_t token = 0; };
@@ -252,6 +253,9 @@ struct nasr_ctx {
   BatchSlot slots[NSLOT];
   BatchSlot* cur = nullptr;                  // the resident batch
   hipStream_t cst = nullptr;                 // copy stream of nasr_stage_batch
+  hipStream_t d2h = nullptr;                 // the step's logits leave on this one, from a snapshot (ctc_forward)
+  hipEvent_t ev_snap = nullptr;
+  DevBuf logits_snap;
   std::mutex slot_mu;                        // slot states (nasr_stage_batch may run on a loader thread)
   int slot_rr = 0;
   // device arrays of the resident batch (inside cur->dmeta / cur->dfeats)

@@ -317,7 +317,19 @@ int ctc_forward(nasr_ctx* h) {
     char* hp = static_cast<char*>(r.host);
     // the step's logits too (before the CTC gradient overwrites them in place): what tf.nn.ctc_beam_search_decoder reads in
     // the reference's train step (tfnetwork.py:61-64,188-189) - the host decodes them while the device runs on
-    if (lg_bytes) HIPCHK(h, hipMemcpyAsync(hp + lg_off, h->logits.p, lg_bytes, hipMemcpyDeviceToHost, h->st));
+    // They leave from a snapshot on a stream of their own: the compute stream pays a 1 MB device copy, not the PCIe transfer.
+    if (lg_bytes) {
+      bool grew = false;
+      if (!h->logits_snap.ensure(lg_bytes, &grew)) return h->fail(NASR_ERR_HIP, "hipMalloc of the logits snapshot failed");
+      if (!r.ev_lg) HIPCHK(h, hipEventCreateWithFlags(&r.ev_lg, hipEventDisableTiming));
+      nasr_ctx::StepRes& prev = h->res[h->res_cur ^ 1];
+      if (prev.logits && prev.ev_lg) HIPCHK(h, hipStreamWaitEvent(h->st, prev.ev_lg, 0));      // the snapshot's last reader (long done)
+      HIPCHK(h, hipMemcpyAsync(h->logits_snap.p, h->logits.p, lg_bytes, hipMemcpyDeviceToDevice, h->st));
+      HIPCHK(h, hipEventRecord(h->ev_snap, h->st));
+      HIPCHK(h, hipStreamWaitEvent(h->d2h, h->ev_snap, 0));
+      HIPCHK(h, hipMemcpyAsync(hp + lg_off, h->logits_snap.p, lg_bytes, hipMemcpyDeviceToHost, h->d2h));
+      HIPCHK(h, hipEventRecord(r.ev_lg, h->d2h));
+    }
     r.logits = lg_bytes != 0;
     r.seq = ++h->stamp_seq;
     launch_publish_results(h->loss.as<float>(), h->Gbase, h->lens.as<int>(), h->Bp, h->ids.as<int>(), h->B * h->Tp, r.host, r.stamp,
