@@ -262,7 +262,9 @@ int nasr_set_step_decode(nasr_handle h, int enabled);
 /* enabled = 3: the step's logits are copied out as well (pinned memory, behind the CTC forward kernels, before the CTC
  * gradient overwrites them): nasr_get_step_logits waits for that copy only and returns them time-major [T',B,C], as
  * nasr_forward does.  The host can then run the reference's own decoder (nasr_ctc_beam_search) for the step's mean_ler
- * while the device runs the backward pass and the steps behind it (tfnetwork.py:61-70,188-189). */
+ * while the device runs the backward pass and the steps behind it (tfnetwork.py:61-70,188-189).  enabled = 2: the same
+ * without the greedy decoder (a host with its own decoder has no use for it): nasr_get_step_results then returns loss and
+ * fault word with empty hypotheses. */
 int nasr_get_step_logits(nasr_handle h, float* logits_out);
 int nasr_get_decoded(nasr_handle h, int32_t* ids_out /*[B,T']*/, int32_t* lens_out /*[B]*/);
 

@@ -740,18 +740,27 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   if (lane == 0) am[row] = bi;
 }
 
-__global__ void collapse_kernel(const int* __restrict__ am, const int* __restrict__ seq_len, int* __restrict__ ids,
-                                int* __restrict__ lens, int Tp, int B, int Bp, int blank) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int n = 0, prev = -1;
+// merge repeats, drop blanks: one wave per utterance, 64 frames per turn (a frame is kept when it differs from the frame before
+// and is no blank; its place is the count of kept frames before it: ballot + popcount) - T/64 turns instead of T dependent
+// loads on one thread (90 us of every training step with the greedy LER at T = 500)
+__global__ __launch_bounds__(64) void collapse_kernel(const int* __restrict__ am, const int* __restrict__ seq_len,
+                                                      int* __restrict__ ids, int* __restrict__ lens, int Tp, int B, int Bp,
+                                                      int blank) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   const int Tb = seq_len[b];
-  for (int t = 0; t < Tb; ++t) {
-    const int k = am[t * Bp + b];
-    if (k != prev && k != blank) ids[(size_t)b * Tp + n++] = k;
-    prev = k;
+  int n = 0, carry = -1;                      // kept so far; the class of the last frame of the turn before
+  for (int t0 = 0; t0 < Tb; t0 += 64) {
+    const int t = t0 + lane;
+    const int k = t < Tb ? am[t * Bp + b] : blank;
+    int prev = __shfl_up(k, 1);
+    if (lane == 0) prev = carry;
+    const bool keep = t < Tb && k != prev && k != blank;
+    const unsigned long long m = __ballot(keep);
+    if (keep) ids[(size_t)b * Tp + n + __popcll(m & ((1ull << lane) - 1ull))] = k;
+    n += __popcll(m);
+    carry = __shfl(k, 63);
   }
-  lens[b] = n;
+  if (lane == 0) lens[b] = n;
 }
 
 void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, int* argmax_ws, int* ids, int* lens,
@@ -759,8 +768,7 @@ void launch_greedy(const CtcDims& d, const float* logits, const int* seq_len, in
   const int rows = d.Tp * d.Bp;
   hipLaunchKernelGGL(argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, seq_len, argmax_ws, d.Tp, d.B, d.Bp,
                      d.C, d.Cp);
-  hipLaunchKernelGGL(collapse_kernel, dim3((d.B + 63) / 64), dim3(64), 0, st, argmax_ws, seq_len, ids, lens, d.Tp, d.B,
-                     d.Bp, d.C - 1);
+  hipLaunchKernelGGL(collapse_kernel, dim3(d.B), dim3(64), 0, st, argmax_ws, seq_len, ids, lens, d.Tp, d.B, d.Bp, d.C - 1);
 }
 
 }  // namespace nasr

@@ -679,6 +679,11 @@ int nasr_get_step_results(nasr_handle h, float* loss_out, int* fault_out, int32_
   memcpy(&fault, hp + 4, 4);
   if (loss_out) memcpy(loss_out, hp, 4);
   if (fault_out) *fault_out = fault != 0.f ? 1 : 0;
+  if (!r.greedy) {                      // nasr_set_step_decode(h, 2): no greedy decode was run - empty hypotheses
+    if (lens_out) memset(lens_out, 0, (size_t)r.B * 4);
+    if (ids_out) memset(ids_out, 0, (size_t)r.B * r.Tp * 4);
+    return NASR_OK;
+  }
   if (lens_out) memcpy(lens_out, hp + 8, (size_t)r.B * 4);
   if (ids_out) memcpy(ids_out, hp + 8 + (size_t)r.Bp * 4, (size_t)r.B * r.Tp * 4);
   return NASR_OK;
@@ -800,6 +805,7 @@ int nasr_greedy_decode(nasr_handle h, const float* feats, const int32_t* seq_len
 int nasr_set_step_decode(nasr_handle h, int enabled) {
   if (!h) return NASR_ERR_ARG;
   h->step_decode = enabled != 0;
+  h->step_greedy = (enabled & 1) != 0;
   h->step_logits = (enabled & 2) != 0;
   return NASR_OK;
 }

@@ -234,7 +234,7 @@ struct nasr_ctx {
   // forward pass, and the greedy decode are copied to pinned memory right behind the CTC forward kernels; the fault
   // word at the END of a step is copied behind its Adam launch (nasr_settle_step).  Two slots each: the host may be
   // one step ahead of the device.
-  struct StepRes { void* host = nullptr; size_t cap = 0; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int B = 0, Bp = 0, Tp = 0; bool logits = false;
+  struct StepRes { void* host = nullptr; size_t cap = 0; uint32_t* stamp = nullptr; uint32_t seq = 0; bool valid = false; int B = 0, Bp = 0, Tp = 0; bool logits = false, greedy = false;
                    hipEvent_t ev_lg = nullptr; };   // ev_lg: the step's logits have landed in host memory (stream d2h)
   StepRes res[2];
   int res_cur = 0;
@@ -294,7 +294,8 @@ struct nasr_ctx {
 
   // graphs
   bool graph_mode = true;
-  bool step_decode = false, step_logits = false, have_decoded = false;   // nasr_set_step_decode: bit 0 / bit 1
+  bool step_decode = false, step_logits = false, have_decoded = false;   // nasr_set_step_decode: any bit / bit 1
+  bool step_greedy = false;                                              // ... bit 0
   std::map<GraphKey, hipGraphExec_t> graphs;
 
   // profiling

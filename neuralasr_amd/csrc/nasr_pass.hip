@@ -304,9 +304,9 @@ int ctc_forward(nasr_ctx* h) {
                         h->boff.as<double>(), h->nll.as<float>(), h->logp.as<double>(), h->st);
   launch_mean(h->nll.as<float>(), h->B, h->loss.as<float>(), h->st);
   if (h->step_decode) {
-    launch_greedy(d, h->logits.as<float>(), h->seq_p, h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(),
-                  h->st);
-    h->have_decoded = true;
+    if (h->step_greedy)
+      launch_greedy(d, h->logits.as<float>(), h->seq_p, h->amax.as<int>(), h->ids.as<int>(), h->lens.as<int>(), h->st);
+    h->have_decoded = h->step_greedy;
     // what Network.train returns is known HERE, before the backward pass: copy it out now (nasr_get_step_results)
     h->res_cur ^= 1;
     nasr_ctx::StepRes& r = h->res[h->res_cur];
@@ -332,8 +332,10 @@ int ctc_forward(nasr_ctx* h) {
     }
     r.logits = lg_bytes != 0;
     r.seq = ++h->stamp_seq;
-    launch_publish_results(h->loss.as<float>(), h->Gbase, h->lens.as<int>(), h->Bp, h->ids.as<int>(), h->B * h->Tp, r.host, r.stamp,
-                           r.seq, h->st);
+    // (enabled = 2: loss, fault word and logits only - the host runs its own decoder and has no use for the greedy one's)
+    launch_publish_results(h->loss.as<float>(), h->Gbase, h->lens.as<int>(), h->step_greedy ? h->Bp : 0, h->ids.as<int>(),
+                           h->step_greedy ? h->B * h->Tp : 0, r.host, r.stamp, r.seq, h->st);
+    r.greedy = h->step_greedy;
     r.valid = true; r.B = h->B; r.Bp = h->Bp; r.Tp = h->Tp;
   }
   HIPCHK(h, hipGetLastError());

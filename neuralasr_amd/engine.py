@@ -270,10 +270,11 @@ class Engine:
             raise _lib.NasrError(rc, 'nasr_label_error_rate: bad arguments')
         return float(out.value)
 
-    def set_step_decode(self, on, logits=False):
-        """Greedy decode of every step's logits (on) and, with logits=True, a copy of the logits themselves for the host
-        (include/nasr.h: nasr_set_step_decode, nasr_get_step_logits)."""
-        self._ck(self.lib.nasr_set_step_decode(self.h, (1 if on else 0) | (2 if (on and logits) else 0)))
+    def set_step_decode(self, on, logits=False, greedy=True):
+        """Per step: loss + greedy decode copied out behind the CTC kernels (on), with logits=True the logits themselves too,
+        with greedy=False (and logits) those without the greedy decode (include/nasr.h: nasr_set_step_decode)."""
+        mode = 0 if not on else ((1 if greedy or not logits else 0) | (2 if logits else 0))
+        self._ck(self.lib.nasr_set_step_decode(self.h, mode))
 
     def step_logits(self, B, T):
         """[T',B,C] logits of the step just enqueued, as soon as its forward pass + CTC are done (the backward pass runs on)."""

@@ -262,7 +262,8 @@ class HipNetwork(Network):
         elif not (self._use_device_context() and
                   self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
             self.engine.upload_batch(f, s, l, ll)
-        self.engine.set_step_decode(True, logits=self.train_ler_decoder == 'beam')
+        beam = self.train_ler_decoder == 'beam'
+        self.engine.set_step_decode(True, logits=beam, greedy=not beam)     # (the beam search reads the logits; no greedy pass then)
         self.engine.compute_grads()
         if self.coll.world > 1:
             if self._grad_tensor is None:
@@ -409,7 +410,8 @@ class HipNetwork(Network):
                 if not (self._use_device_context() and
                         self.engine.upload_batch_context(f, s, l, ll, self.config.numcontext, self.config.numcep)):
                     self.engine.upload_batch(f, s, l, ll)
-                self.engine.set_step_decode(True, logits=self.train_ler_decoder == 'beam')
+                beam = self.train_ler_decoder == 'beam'
+                self.engine.set_step_decode(True, logits=beam, greedy=not beam)
                 self.engine.compute_grads()
                 try:
                     losses.append(self.engine.get_loss())
