@@ -565,3 +565,27 @@ def test_train_model_logs_the_beam_ler_of_every_step(tmp_path, caplog):
     assert len(lines) == len(lers) // 3 and len(lines) >= 1
     for i, ln in enumerate(lines):
         assert ', ler = %.4f' % np.mean(lers[3 * i:3 * i + 3]) in ln, (ln, lers)
+
+
+def test_step_results_with_logits_only():
+    """nasr_set_step_decode(h, 2): the step's loss, fault word and logits behind the CTC kernels, no greedy decode (what the
+    beam-LER train step uses) - same loss and logits as mode 3, empty hypotheses, and the gradients are not disturbed."""
+    from neuralasr_amd.engine import Engine
+    spec = O.ModelSpec(9, 24, 2, True, 'concat', 7)
+    feats, seq_len, labels, label_len = O.synth_batch(spec, 5, 23, seed=3, var_len=True, Lmin=1, Lmax=5)
+    e = Engine(spec.feature_size, spec.hidden, spec.num_layers, spec.bidirectional, spec.merge, spec.num_classes)
+    e.set_params(O.flatten(O.init_params(spec, seed=2)))
+    e.upload_batch(feats, seq_len, labels, label_len)
+    out = {}
+    for greedy in (True, False):
+        e.set_step_decode(True, logits=True, greedy=greedy)
+        e.compute_grads()
+        loss, fault, hyps = e.step_results(5, 23)
+        out[greedy] = (loss, fault, hyps, e.step_logits(5, 23), e.get_grads())
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1] == 0
+    np.testing.assert_array_equal(out[True][3], out[False][3])
+    np.testing.assert_array_equal(out[True][4], out[False][4])
+    np.testing.assert_allclose(out[True][3], e.forward(feats, seq_len), atol=1e-6)
+    assert any(len(h) for h in out[True][2]) and not any(len(h) for h in out[False][2])
+    assert out[True][2] == e.greedy_decode(feats, seq_len)
+    e.close()
