@@ -1,6 +1,6 @@
 // persistbench.hip — the persistent recurrence (lstm_persist.hip) against the per-step kernels (lstm.hip) on the same
 // random layer: max-abs differences of every buffer both write, and time per step of each.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/persistbench.hip neuralasr_amd/csrc/lstm.hip neuralasr_amd/csrc/lstm_persist.hip -o tools/sb_persist
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/persistbench.hip neuralasr_amd/csrc/lstm.hip neuralasr_amd/csrc/lstm_persist.hip neuralasr_amd/csrc/optim.hip -o tools/sb_persist
 //   tools/sb_persist [H=500] [B=16] [T=500] [D=2] [ragged=1]
 #include "../neuralasr_amd/csrc/kernels.h"
 #include <algorithm>
